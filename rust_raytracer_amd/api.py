@@ -1,0 +1,312 @@
+"""ctypes mirror of include/rt_mi355.h and include/rt_host.h.
+
+The product path is `librt_mi355.so` (HIP kernels behind the C ABI) plus `librt_host.so`
+(CLI flags, scene DSL, OBJ loader, camera, output stage).  There is NO CPU fallback: if the
+HIP library is missing, `load_device_lib()` raises.  The CPU oracle under oracle/ is test
+infrastructure and is never loaded from this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+
+RT_OK = 0
+RT_E_INVALID, RT_E_UNSUPPORTED, RT_E_DEVICE, RT_E_NOMEM = -1, -2, -3, -4
+RT_PRECISION_F64, RT_PRECISION_F32 = 0, 1
+RT_PIPELINE_AUTO, RT_PIPELINE_MEGAKERNEL, RT_PIPELINE_WAVEFRONT = 0, 1, 2
+
+(RT_NODE_SPHERE, RT_NODE_PLANE, RT_NODE_MESH, RT_NODE_LIST, RT_NODE_TRANSFORM, RT_NODE_BVH,
+ RT_NODE_SKY, RT_NODE_SUN, RT_NODE_VOLUME, RT_NODE_NULL) = range(1, 11)
+(RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_GLOSSY, RT_MAT_EMISSIVE,
+ RT_MAT_ISOTROPIC, RT_MAT_NORMAL_DEBUG) = range(1, 8)
+(RT_TEX_CONST_COLOR, RT_TEX_CONST_FLOAT, RT_TEX_CHECKER, RT_TEX_CHECKER_SOLID, RT_TEX_LERP,
+ RT_TEX_IMAGE, RT_TEX_NOISE_SOLID, RT_TEX_CHANNEL, RT_TEX_UV_DEBUG) = range(1, 10)
+
+
+class RtNode(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("flags", C.c_uint32), ("material", C.c_int32),
+                ("mesh", C.c_int32), ("transform", C.c_int32), ("first_child", C.c_uint32),
+                ("n_children", C.c_uint32), ("_pad", C.c_uint32),
+                ("bounds", C.c_double * 6), ("p", C.c_double * 12)]
+
+
+class RtTransform(C.Structure):
+    _fields_ = [("m", C.c_double * 16), ("inv", C.c_double * 16)]
+
+
+class RtMesh(C.Structure):
+    _fields_ = [("positions", C.POINTER(C.c_double)), ("normals", C.POINTER(C.c_double)),
+                ("uvs", C.POINTER(C.c_double)), ("tri_pos", C.POINTER(C.c_uint32)),
+                ("tri_nrm", C.POINTER(C.c_uint32)), ("tri_uv", C.POINTER(C.c_int32)),
+                ("n_positions", C.c_uint32), ("n_normals", C.c_uint32), ("n_uvs", C.c_uint32),
+                ("n_triangles", C.c_uint32), ("flags", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class RtMaterial(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("tex_a", C.c_int32), ("tex_b", C.c_int32),
+                ("tex_c", C.c_int32), ("ior", C.c_double)]
+
+
+class RtTexture(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_int32),
+                ("channel", C.c_uint32), ("_pad", C.c_uint32), ("v", C.c_double * 3),
+                ("scale", C.c_double)]
+
+
+class RtSceneDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("n_nodes", C.c_uint32),
+                ("nodes", C.POINTER(RtNode)),
+                ("n_child_indices", C.c_uint32), ("n_transforms", C.c_uint32),
+                ("child_indices", C.POINTER(C.c_uint32)),
+                ("transforms", C.POINTER(RtTransform)),
+                ("n_meshes", C.c_uint32), ("n_materials", C.c_uint32),
+                ("meshes", C.POINTER(RtMesh)), ("materials", C.POINTER(RtMaterial)),
+                ("n_textures", C.c_uint32), ("world_root", C.c_uint32),
+                ("textures", C.POINTER(RtTexture)),
+                ("lights_root", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class RtCameraDesc(C.Structure):
+    _fields_ = [("image_width", C.c_uint32), ("image_height", C.c_uint32),
+                ("position", C.c_double * 3), ("first_pixel", C.c_double * 3),
+                ("pixel_delta_u", C.c_double * 3), ("pixel_delta_v", C.c_double * 3),
+                ("basis_u", C.c_double * 3), ("basis_v", C.c_double * 3),
+                ("has_aperture", C.c_uint32), ("_pad", C.c_uint32),
+                ("aperture_radius", C.c_double)]
+
+
+class RtRenderParams(C.Structure):
+    _fields_ = [("sqrt_spt", C.c_uint32), ("thread_count", C.c_uint32),
+                ("max_depth", C.c_uint32), ("has_background", C.c_uint32),
+                ("light_bias", C.c_double), ("background", C.c_double * 3),
+                ("seed", C.c_uint64),
+                ("band_rows", C.c_uint32), ("n_parts", C.c_uint32), ("part", C.c_uint32),
+                ("precision", C.c_uint32), ("pipeline", C.c_uint32),
+                ("collect_stats", C.c_uint32)]
+
+    def copy(self) -> "RtRenderParams":
+        out = RtRenderParams()
+        C.memmove(C.byref(out), C.byref(self), C.sizeof(RtRenderParams))
+        return out
+
+    @property
+    def spp(self) -> int:
+        return self.sqrt_spt * self.sqrt_spt * self.thread_count
+
+
+class RtRenderStats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("traversal_kernel_ms", C.c_double),
+                ("n_launches", C.c_uint32), ("pipeline_used", C.c_uint32),
+                ("samples", C.c_uint64), ("rays", C.c_uint64), ("mesh_rays", C.c_uint64),
+                ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("prim_tests", C.c_uint64), ("bytes_node", C.c_uint64),
+                ("bytes_tri", C.c_uint64), ("bytes_attr", C.c_uint64),
+                ("bytes_state", C.c_uint64)]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class RtError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"rt status {status}: {message}")
+        self.status = status
+
+
+HOST_LIB_PATH = os.path.join(PKG_DIR, "librt_host.so")
+DEVICE_LIB_PATH = os.path.join(PKG_DIR, "librt_mi355.so")
+
+_host_lib = None
+_device_lib = None
+
+
+def load_host_lib() -> C.CDLL:
+    global _host_lib
+    if _host_lib is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise FileNotFoundError(
+                f"{HOST_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(HOST_LIB_PATH)
+        lib.rth_load.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
+        lib.rth_load.restype = C.c_int
+        lib.rth_destroy.argtypes = [C.c_void_p]
+        lib.rth_destroy.restype = None
+        lib.rth_scene.argtypes = [C.c_void_p]
+        lib.rth_scene.restype = C.POINTER(RtSceneDesc)
+        lib.rth_camera.argtypes = [C.c_void_p]
+        lib.rth_camera.restype = C.POINTER(RtCameraDesc)
+        lib.rth_params.argtypes = [C.c_void_p]
+        lib.rth_params.restype = C.POINTER(RtRenderParams)
+        lib.rth_gpus.argtypes = [C.c_void_p]
+        lib.rth_gpus.restype = C.c_uint32
+        lib.rth_samples_per_pixel.argtypes = [C.c_void_p]
+        lib.rth_samples_per_pixel.restype = C.c_uint32
+        lib.rth_log.argtypes = [C.c_void_p]
+        lib.rth_log.restype = C.c_char_p
+        lib.rth_make_camera.argtypes = [C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_double,
+                                        C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                        C.POINTER(RtCameraDesc)]
+        lib.rth_make_camera.restype = C.c_int
+        lib.rth_tonemap_rgb8.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        lib.rth_tonemap_rgb8.restype = C.c_int
+        lib.rth_save_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.rth_save_png.restype = C.c_int
+        lib.rth_last_error.argtypes = []
+        lib.rth_last_error.restype = C.c_char_p
+        _host_lib = lib
+    return _host_lib
+
+
+def load_device_lib() -> C.CDLL:
+    """Loads the HIP library.  Raises if it has not been built: there is no fallback."""
+    global _device_lib
+    if _device_lib is None:
+        if not os.path.exists(DEVICE_LIB_PATH):
+            raise FileNotFoundError(
+                f"{DEVICE_LIB_PATH} is missing — the HIP render path was not built "
+                "(run __graft_entry__.build()); refusing to fall back to any CPU path")
+        lib = C.CDLL(DEVICE_LIB_PATH)
+        lib.rt_device_count.argtypes = []
+        lib.rt_device_count.restype = C.c_int
+        lib.rt_scene_create.argtypes = [C.POINTER(RtSceneDesc), C.c_int, C.POINTER(C.c_void_p)]
+        lib.rt_scene_create.restype = C.c_int
+        lib.rt_scene_destroy.argtypes = [C.c_void_p]
+        lib.rt_scene_destroy.restype = None
+        lib.rt_owned_rows.argtypes = [C.c_uint32, C.POINTER(RtRenderParams)]
+        lib.rt_owned_rows.restype = C.c_uint32
+        lib.rt_render.argtypes = [C.c_void_p, C.POINTER(RtCameraDesc), C.POINTER(RtRenderParams), C.c_void_p]
+        lib.rt_render.restype = C.c_int
+        lib.rt_render_device.argtypes = [C.c_void_p, C.POINTER(RtCameraDesc), C.POINTER(RtRenderParams),
+                                         C.c_void_p, C.c_void_p]
+        lib.rt_render_device.restype = C.c_int
+        lib.rt_get_stats.argtypes = [C.c_void_p, C.POINTER(RtRenderStats)]
+        lib.rt_get_stats.restype = C.c_int
+        lib.rt_last_error.argtypes = []
+        lib.rt_last_error.restype = C.c_char_p
+        _device_lib = lib
+    return _device_lib
+
+
+def owned_rows(height: int, params: RtRenderParams) -> list:
+    """Rows of the frame that the partition in `params` assigns to this part (rt_owned_rows)."""
+    if params.band_rows == 0 or params.n_parts <= 1:
+        return list(range(height))
+    return [y for y in range(height) if (y // params.band_rows) % params.n_parts == params.part]
+
+
+class HostScene:
+    """`(Camera, world, lights)` as loaded by the reference's main() (src/main.rs:26-59)."""
+
+    def __init__(self, args: Sequence[str], cwd: Optional[str] = None):
+        lib = load_host_lib()
+        argv = [b"rtrace"] + [a.encode() for a in args]
+        arr = (C.c_char_p * len(argv))(*argv)
+        handle = C.c_void_p()
+        old = os.getcwd()
+        try:
+            os.chdir(cwd or REPO_DIR)  # scene/asset paths are relative to the CWD, like the reference
+            st = lib.rth_load(len(argv), arr, C.byref(handle))
+        finally:
+            os.chdir(old)
+        if st != RT_OK:
+            raise RtError(st, lib.rth_last_error().decode())
+        self._lib = lib
+        self._h = handle
+        self.desc = lib.rth_scene(handle)          # POINTER(RtSceneDesc)
+        self.camera = lib.rth_camera(handle).contents
+        self.params = lib.rth_params(handle).contents.copy()
+        self.gpus = lib.rth_gpus(handle)
+        self.spp = lib.rth_samples_per_pixel(handle)
+        self.log = lib.rth_log(handle).decode()
+
+    @property
+    def width(self) -> int:
+        return self.camera.image_width
+
+    @property
+    def height(self) -> int:
+        return self.camera.image_height
+
+    def close(self):
+        if self._h:
+            self._lib.rth_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def tonemap_rgb8(rgba: np.ndarray) -> np.ndarray:
+    """ACES + sRGB + 8-bit quantisation of an (H, W, 4) f64 frame -> (H, W, 3) uint8."""
+    lib = load_host_lib()
+    rgba = np.ascontiguousarray(rgba, dtype=np.float64)
+    h, w = rgba.shape[:2]
+    out = np.empty((h, w, 3), dtype=np.uint8)
+    st = lib.rth_tonemap_rgb8(rgba.ctypes.data, w, h, out.ctypes.data)
+    if st != RT_OK:
+        raise RtError(st, lib.rth_last_error().decode())
+    return out
+
+
+def save_png(path: str, rgba: np.ndarray) -> None:
+    lib = load_host_lib()
+    rgba = np.ascontiguousarray(rgba, dtype=np.float64)
+    h, w = rgba.shape[:2]
+    st = lib.rth_save_png(path.encode(), rgba.ctypes.data, w, h)
+    if st != RT_OK:
+        raise RtError(st, lib.rth_last_error().decode())
+
+
+class DeviceScene:
+    """RtScene on one GPU: the drop-in for `camera.render(world, lights, &mut buf)`."""
+
+    def __init__(self, desc, device: int = 0):
+        lib = load_device_lib()
+        handle = C.c_void_p()
+        st = lib.rt_scene_create(desc, device, C.byref(handle))
+        if st != RT_OK:
+            raise RtError(st, lib.rt_last_error().decode())
+        self._lib = lib
+        self._h = handle
+        self.device = device
+
+    def render(self, camera: RtCameraDesc, params: RtRenderParams) -> np.ndarray:
+        rows = self._lib.rt_owned_rows(camera.image_height, C.byref(params))
+        out = np.empty((rows, camera.image_width, 4), dtype=np.float64)
+        st = self._lib.rt_render(self._h, C.byref(camera), C.byref(params), out.ctypes.data)
+        if st != RT_OK:
+            raise RtError(st, self._lib.rt_last_error().decode())
+        return out
+
+    def render_device(self, camera: RtCameraDesc, params: RtRenderParams, d_out_ptr: int, stream: int = 0) -> None:
+        st = self._lib.rt_render_device(self._h, C.byref(camera), C.byref(params),
+                                        C.c_void_p(d_out_ptr), C.c_void_p(stream))
+        if st != RT_OK:
+            raise RtError(st, self._lib.rt_last_error().decode())
+
+    def stats(self) -> RtRenderStats:
+        s = RtRenderStats()
+        st = self._lib.rt_get_stats(self._h, C.byref(s))
+        if st != RT_OK:
+            raise RtError(st, self._lib.rt_last_error().decode())
+        return s
+
+    def close(self):
+        if self._h:
+            self._lib.rt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
