@@ -239,6 +239,14 @@ int rt_render_device(const RtScene* scene, const RtCameraDesc* camera,
 
 int rt_get_stats(const RtScene* scene, RtRenderStats* out);
 
+/* Diagnostic probe (tests): traces ONE sample (replica tid, pixel x,y, stratum sx,sy) on the
+ * device; rgb_out[3] = its radiance, trace_out[8*max_bounces] = per bounce: t, pos xyz,
+ * material index, scene-program op type, normal x, normal y.  Returns the bounce count (>= 0)
+ * or a negative RtStatus. */
+int rt_debug_trace_sample(const RtScene* scene, const RtCameraDesc* camera, const RtRenderParams* params,
+                          uint32_t tid, uint32_t x, uint32_t y, uint32_t sx, uint32_t sy,
+                          double* rgb_out, double* trace_out, uint32_t max_bounces);
+
 /* Message for the last non-RT_OK status on this thread ("" if none). */
 const char* rt_last_error(void);
 

@@ -1182,6 +1182,10 @@ std::unique_ptr<World> build_world(const RtSceneDesc* d) {
     return w;
 }
 
+// Optional per-bounce trace (debugging / tests): 8 doubles per bounce:
+// t, pos.xyz, material index, scatter kind (0 pdf, 1 ray, 2 absorbed, 3 emissive, -1 miss), pdf, scattering_pdf
+thread_local std::vector<double>* g_trace = nullptr;
+
 // ------------------------------------------------------------------ camera.rs
 struct Camera {
     RtCameraDesc c;
@@ -1226,6 +1230,12 @@ struct Camera {
         if (object->test(ray, {0.001, INF}, rng, hit)) {
             Vec4 from_emission = hit.material->emit(hit);
             ScatterResult sr = hit.material->scatter(ray, hit, rng);
+            size_t trace_at = 0;
+            if (g_trace) {
+                trace_at = g_trace->size();
+                g_trace->insert(g_trace->end(), {hit.t, hit.hit_pos[0], hit.hit_pos[1], hit.hit_pos[2],
+                                                 double(hit.material_index), double(int(sr.kind)), 0.0, 0.0});
+            }
             switch (sr.kind) {
                 case ScatterKind::WithPDF: {
                     lights_pdf.origin = hit.hit_pos;
@@ -1236,6 +1246,7 @@ struct Camera {
                     Ray scattered(hit.hit_pos, mix_pdf.generate(rng));
                     double pdf = mix_pdf.value(scattered.dir, rng);
                     double scattering_pdf = hit.material->scattering_pdf(ray, scattered, hit);
+                    if (g_trace) { (*g_trace)[trace_at + 6] = pdf; (*g_trace)[trace_at + 7] = scattering_pdf; }
                     Vec4 scatter_color = ray_color(scattered, object, lights_pdf, depth - 1, rng);
                     Vec4 from_scatter = (scatter_color * sr.attenuation * scattering_pdf) / pdf;
                     return from_emission + from_scatter;
@@ -1251,6 +1262,7 @@ struct Camera {
                     return from_emission;
             }
         }
+        if (g_trace) g_trace->insert(g_trace->end(), {INF, 0, 0, 0, -1, -1, 0, 0});
         return background;
     }
 };
@@ -1431,6 +1443,30 @@ void oracle_rng_raw(uint64_t seed, uint32_t tid, uint64_t pixel, uint32_t stratu
     Rng rng;
     rng.key(seed, tid, pixel, stratum);
     for (uint32_t i = 0; i < n; i++) out[i] = rng.next();
+}
+
+int oracle_trace_sample(const RtSceneDesc* scene, const RtCameraDesc* camera, const RtRenderParams* params,
+                        uint32_t tid, uint32_t x, uint32_t y, uint32_t sx, uint32_t sy, double* rgb_out,
+                        double* trace_out, uint32_t max_bounces) {
+    g_err.clear();
+    auto world = build_world(scene);
+    if (!world) return RT_E_INVALID;
+    Camera cam(*camera, *params);
+    HittablePDF lights_pdf;
+    lights_pdf.object = world->lights;
+    lights_pdf.origin = point(0.0, 0.0, 0.0);
+    Rng rng;
+    rng.key(params->seed, tid, uint64_t(y) * camera->image_width + x, sy * params->sqrt_spt + sx);
+    Ray ray = cam.get_ray(x, y, sx, sy, rng);
+    std::vector<double> trace;
+    g_trace = &trace;
+    Vec4 c = cam.ray_color(ray, world->world, lights_pdf, params->max_depth, rng);
+    g_trace = nullptr;
+    rgb_out[0] = c[0]; rgb_out[1] = c[1]; rgb_out[2] = c[2];
+    uint32_t n = uint32_t(trace.size() / 8);
+    for (uint32_t i = 0; i < n && i < max_bounces; i++)
+        for (int k = 0; k < 8; k++) trace_out[8 * i + k] = trace[8 * i + k];
+    return int(n);
 }
 
 void oracle_get_ray(const RtCameraDesc* camera, const RtRenderParams* params, uint32_t tid, uint32_t x, uint32_t y,

@@ -72,6 +72,13 @@ void oracle_rng_raw(uint64_t seed, uint32_t tid, uint64_t pixel, uint32_t stratu
 void oracle_get_ray(const RtCameraDesc* camera, const RtRenderParams* params, uint32_t tid,
                     uint32_t x, uint32_t y, uint32_t sx, uint32_t sy, double* out6);
 
+/* ray_color for ONE sample with a per-bounce trace (8 doubles per bounce: t, pos xyz, material,
+ * scatter kind 0 pdf / 1 ray / 2 absorbed / 3 emissive / -1 miss, mix pdf, scattering pdf).
+ * Returns the number of bounces recorded. */
+int oracle_trace_sample(const RtSceneDesc* scene, const RtCameraDesc* camera, const RtRenderParams* params,
+                        uint32_t tid, uint32_t x, uint32_t y, uint32_t sx, uint32_t sy, double* rgb_out,
+                        double* trace_out, uint32_t max_bounces);
+
 const char* oracle_last_error(void);
 
 #ifdef __cplusplus

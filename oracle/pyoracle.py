@@ -64,6 +64,10 @@ def load() -> C.CDLL:
         lib.oracle_get_ray.argtypes = [C.POINTER(api.RtCameraDesc), C.POINTER(api.RtRenderParams), C.c_uint32,
                                        C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, dp]
         lib.oracle_get_ray.restype = None
+        lib.oracle_trace_sample.argtypes = [C.POINTER(api.RtSceneDesc), C.POINTER(api.RtCameraDesc),
+                                            C.POINTER(api.RtRenderParams), C.c_uint32, C.c_uint32, C.c_uint32,
+                                            C.c_uint32, C.c_uint32, dp, dp, C.c_uint32]
+        lib.oracle_trace_sample.restype = C.c_int
         lib.oracle_last_error.argtypes = []
         lib.oracle_last_error.restype = C.c_char_p
         _lib = lib
@@ -151,3 +155,14 @@ def get_ray(camera, params, tid, x, y, sx, sy) -> np.ndarray:
     out = (C.c_double * 6)()
     lib.oracle_get_ray(C.byref(camera), C.byref(params), tid, x, y, sx, sy, out)
     return np.array(list(out))
+
+
+def trace_sample(desc, camera, params, tid, x, y, sx, sy, max_bounces=64):
+    """(rgb, trace[n, 8]) of one sample; see oracle.h oracle_trace_sample."""
+    lib = load()
+    rgb = (C.c_double * 3)()
+    tr = (C.c_double * (8 * max_bounces))()
+    n = lib.oracle_trace_sample(desc, C.byref(camera), C.byref(params), tid, x, y, sx, sy, rgb, tr, max_bounces)
+    if n < 0:
+        raise api.RtError(n, lib.oracle_last_error().decode())
+    return np.array(list(rgb)), np.array(list(tr)).reshape(max_bounces, 8)[:min(n, max_bounces)]

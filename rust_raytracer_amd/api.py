@@ -187,6 +187,10 @@ def load_device_lib() -> C.CDLL:
         lib.rt_render_device.restype = C.c_int
         lib.rt_get_stats.argtypes = [C.c_void_p, C.POINTER(RtRenderStats)]
         lib.rt_get_stats.restype = C.c_int
+        lib.rt_debug_trace_sample.argtypes = [C.c_void_p, C.POINTER(RtCameraDesc), C.POINTER(RtRenderParams),
+                                              C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_uint32]
+        lib.rt_debug_trace_sample.restype = C.c_int
         lib.rt_last_error.argtypes = []
         lib.rt_last_error.restype = C.c_char_p
         _device_lib = lib
@@ -292,6 +296,16 @@ class DeviceScene:
                                         C.c_void_p(d_out_ptr), C.c_void_p(stream))
         if st != RT_OK:
             raise RtError(st, self._lib.rt_last_error().decode())
+
+    def trace_sample(self, camera, params, tid, x, y, sx, sy, max_bounces=64):
+        """Diagnostic: (rgb[3], trace[n, 8]) of one sample traced on the device."""
+        rgb = (C.c_double * 3)()
+        tr = (C.c_double * (8 * max_bounces))()
+        n = self._lib.rt_debug_trace_sample(self._h, C.byref(camera), C.byref(params), tid, x, y, sx, sy,
+                                            rgb, tr, max_bounces)
+        if n < 0:
+            raise RtError(n, self._lib.rt_last_error().decode())
+        return np.array(list(rgb)), np.array(list(tr)).reshape(max_bounces, 8)[:min(n, max_bounces)]
 
     def stats(self) -> RtRenderStats:
         s = RtRenderStats()

@@ -1,0 +1,101 @@
+"""Builds the native libraries in-tree (the built .so files travel to the GPU box with the
+repo snapshot).  hipcc cross-compiles for gfx950 without a GPU.
+
+    python -m rust_raytracer_amd.build            # everything
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, "csrc")
+HOST_SRC = ["scene_builder.cpp", "obj_loader.cpp", "config.cpp", "dsl_loader.cpp", "default_scene.cpp",
+            "output.cpp", "host_api.cpp"]
+DEVICE_SRC = ["rt_kernels.hip", "rt_compile.cpp", "rt_bvh.cpp"]
+DEVICE_HDR = ["rt_device.h", "rt_scene.h", "rt_compile.h", "rt_bvh.h"]
+
+
+def _newer(target: str, sources) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd, cwd=None):
+    r = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"command failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    return r
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def build_host(force: bool = False) -> str:
+    out = os.path.join(PKG_DIR, "librt_host.so")
+    hdir = os.path.join(CSRC, "host")
+    srcs = [os.path.join(hdir, s) for s in HOST_SRC]
+    deps = srcs + [os.path.join(hdir, h) for h in ("hmath.h", "scene_builder.h", "host_internal.h")] + \
+        [os.path.join(REPO_DIR, "include", h) for h in ("rt_mi355.h", "rt_host.h")]
+    if force or _newer(out, deps):
+        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-o", out] + srcs + ["-lz"])
+    return out
+
+
+def build_cli(force: bool = False) -> str:
+    """The `rtrace` executable: drop-in for the reference binary (same flags, DSL, out.png)."""
+    out = os.path.join(PKG_DIR, "rtrace")
+    src = os.path.join(CSRC, "host", "main.cpp")
+    if not os.path.exists(src):
+        return ""
+    deps = [src, os.path.join(PKG_DIR, "librt_host.so"), os.path.join(PKG_DIR, "librt_mi355.so")]
+    if force or _newer(out, deps):
+        _run([hipcc_path(), "-std=c++17", "-O2", "-o", out, src, "-L" + PKG_DIR, "-lrt_host", "-lrt_mi355",
+              "-Wl,-rpath,$ORIGIN", "-lpthread"])
+    return out
+
+
+def build_device(force: bool = False) -> str:
+    out = os.path.join(PKG_DIR, "librt_mi355.so")
+    srcs = [os.path.join(CSRC, s) for s in DEVICE_SRC]
+    deps = srcs + [os.path.join(CSRC, h) for h in DEVICE_HDR] + [os.path.join(REPO_DIR, "include", "rt_mi355.h")]
+    if force or _newer(out, deps):
+        _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+              "-Wall", "-Wno-unused-function", "-o", out] + srcs)
+    return out
+
+
+def build_oracle(force: bool = False) -> str:
+    odir = os.path.join(REPO_DIR, "oracle")
+    out = os.path.join(odir, "liboracle.so")
+    deps = [os.path.join(odir, "oracle.cpp"), os.path.join(odir, "oracle.h"),
+            os.path.join(REPO_DIR, "include", "rt_mi355.h")]
+    if force or _newer(out, deps):
+        _run(["make", "-C", odir, "-B", "liboracle.so"])
+    return out
+
+
+def build_tools(force: bool = False) -> str:
+    out = os.path.join(REPO_DIR, "tools", "gen_dragon")
+    src = os.path.join(REPO_DIR, "tools", "gen_dragon.cpp")
+    if os.path.exists(src) and (force or _newer(out, [src])):
+        _run(["g++", "-std=c++17", "-O2", "-o", out, src])
+    return out
+
+
+def build_all(force: bool = False):
+    return {"host": build_host(force), "device": build_device(force), "cli": build_cli(force),
+            "oracle": build_oracle(force), "tools": build_tools(force)}
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv))

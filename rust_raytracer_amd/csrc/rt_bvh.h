@@ -1,0 +1,28 @@
+// rt_bvh.h — host-side binned-SAH BVH2 builder for one triangle mesh.
+//
+// Replaces the reference's octree (src/object/mesh/octree.rs:31-210: midpoint split into 8
+// octants, <= 50 triangles per leaf, triangles duplicated into every octant they touch,
+// children visited in fixed order).  Any structure that returns the same closest hit is
+// admissible: the octree only culls; ties between different triangles at exactly
+// equal t may resolve to a different (adjacent) triangle.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace rt {
+
+struct BuildNode {
+    double lo0[3], hi0[3], lo1[3], hi1[3];
+    int32_t c0, c1;  // encoding: see BvhNode in rt_scene.h
+};
+
+struct BvhBuild {
+    std::vector<BuildNode> nodes;     // nodes[0] is the root
+    std::vector<uint32_t> tri_order;  // leaf order -> original triangle index
+    uint32_t max_depth = 0;           // number of inner-node levels (bounds the traversal stack)
+};
+
+// positions: n_positions*3 doubles; tri_pos: n_tris*3 indices.  max_leaf in 1..8.
+BvhBuild build_bvh(const double* positions, const uint32_t* tri_pos, uint32_t n_tris, uint32_t max_leaf);
+
+}  // namespace rt

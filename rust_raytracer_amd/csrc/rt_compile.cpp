@@ -1,0 +1,394 @@
+// Scene compiler: walks the Hit tree of an RtSceneDesc depth-first — the order in which the
+// reference's recursive `test()` calls visit it — and emits the linear scene program plus the
+// primitive / mesh / material / light tables of rt_scene.h.  Host, one-shot, f64.
+#include "rt_compile.h"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+
+namespace rt {
+namespace {
+
+struct V3 {
+    double x, y, z;
+};
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+inline V3 operator/(V3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline double length(V3 a) { return std::sqrt(dot(a, a)); }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline void put(double d[3], V3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+
+struct Compiler {
+    const RtSceneDesc& d;
+    CompiledScene& out;
+    std::string* err;
+    int status = RT_OK;
+    std::vector<int32_t> chain;                      // transforms enclosing the current position
+    std::map<std::vector<int32_t>, int32_t> chain_ids;
+    std::vector<std::vector<int32_t>> chains;
+    std::map<uint32_t, int32_t> sphere_of_node, plane_of_node, sun_of_node;
+    std::map<int32_t, std::pair<uint32_t, uint32_t>> mesh_geometry;  // RtMesh index -> (node_base, tri_base)
+    std::map<int32_t, uint32_t> mesh_depth;
+    std::map<int32_t, int32_t> xform_of;             // RtTransform index -> xforms index
+
+    bool fail(int st, const std::string& msg) {
+        if (status == RT_OK) {
+            status = st;
+            *err = msg;
+        }
+        return false;
+    }
+
+    int32_t chain_id() {
+        auto it = chain_ids.find(chain);
+        if (it != chain_ids.end()) return it->second;
+        int32_t id = int32_t(chains.size());
+        chains.push_back(chain);
+        chain_ids[chain] = id;
+        return id;
+    }
+
+    void emit(int32_t type, int32_t arg) { out.ops.push_back({type, arg, 0, chain_id()}); }
+
+    bool check_material(int32_t m) {
+        if (m < 0 || uint32_t(m) >= d.n_materials) return fail(RT_E_INVALID, "material index out of range");
+        return true;
+    }
+
+    int32_t sphere_index(uint32_t node) {
+        auto it = sphere_of_node.find(node);
+        if (it != sphere_of_node.end()) return it->second;
+        const RtNode& n = d.nodes[node];
+        if (!check_material(n.material)) return -1;
+        SpherePrim<double> s{};
+        s.center[0] = n.p[0]; s.center[1] = n.p[1]; s.center[2] = n.p[2];
+        s.radius = n.p[3];
+        s.material = n.material;
+        out.spheres.push_back(s);
+        return sphere_of_node[node] = int32_t(out.spheres.size()) - 1;
+    }
+
+    // Plane::new, reference src/object/plane.rs:29-63, same operation order.
+    int32_t plane_index(uint32_t node) {
+        auto it = plane_of_node.find(node);
+        if (it != plane_of_node.end()) return it->second;
+        const RtNode& n = d.nodes[node];
+        if (!check_material(n.material)) return -1;
+        V3 center{n.p[0], n.p[1], n.p[2]}, u{n.p[3], n.p[4], n.p[5]}, v{n.p[6], n.p[7], n.p[8]};
+        if (dot(u, v) != 0.0) { fail(RT_E_INVALID, "plane: the UV vectors must be orthogonal (plane.rs:30)"); return -1; }
+        V3 u_unit = u / length(u);
+        V3 v_unit = v / length(v);
+        V3 nn = cross(u, v);
+        PlanePrim<double> p{};
+        p.area = length(nn) * 4.0;
+        put(p.normal, nn / length(nn));
+        put(p.corner, (center - u) - v);
+        put(p.u, u);
+        put(p.v, v);
+        put(p.inv_u, (u_unit * 0.5) / length(u));
+        put(p.inv_v, (v_unit * 0.5) / length(v));
+        p.material = n.material;
+        p.backface = (n.flags & RT_PLANE_RENDER_BACKFACE) ? 1 : 0;
+        out.planes.push_back(p);
+        return plane_of_node[node] = int32_t(out.planes.size()) - 1;
+    }
+
+    int32_t sun_index(uint32_t node) {
+        auto it = sun_of_node.find(node);
+        if (it != sun_of_node.end()) return it->second;
+        const RtNode& n = d.nodes[node];
+        if (!check_material(n.material)) return -1;
+        SunPrim<double> s{};
+        s.direction[0] = n.p[0]; s.direction[1] = n.p[1]; s.direction[2] = n.p[2];
+        s.material = n.material;
+        out.suns.push_back(s);
+        return sun_of_node[node] = int32_t(out.suns.size()) - 1;
+    }
+
+    int32_t xform_index(int32_t t) {
+        if (t < 0 || uint32_t(t) >= d.n_transforms) { fail(RT_E_INVALID, "transform index out of range"); return -1; }
+        auto it = xform_of.find(t);
+        if (it != xform_of.end()) return it->second;
+        const RtTransform& tr = d.transforms[t];
+        const double last[4] = {0, 0, 0, 1};
+        if (std::memcmp(tr.m + 12, last, sizeof last) != 0 || std::memcmp(tr.inv + 12, last, sizeof last) != 0) {
+            fail(RT_E_UNSUPPORTED, "projective transform (last row != 0,0,0,1)");
+            return -1;
+        }
+        Xform<double> x;
+        std::memcpy(x.m, tr.m, sizeof x.m);
+        std::memcpy(x.inv, tr.inv, sizeof x.inv);
+        out.xforms.push_back(x);
+        return xform_of[t] = int32_t(out.xforms.size()) - 1;
+    }
+
+    bool mesh_geometry_for(int32_t mi, uint32_t* node_base, uint32_t* tri_base, uint32_t* depth) {
+        auto it = mesh_geometry.find(mi);
+        if (it != mesh_geometry.end()) {
+            *node_base = it->second.first;
+            *tri_base = it->second.second;
+            *depth = mesh_depth[mi];
+            return true;
+        }
+        const RtMesh& m = d.meshes[mi];
+        if ((m.n_triangles && (!m.positions || !m.tri_pos || !m.tri_nrm || !m.normals)))
+            return fail(RT_E_INVALID, "mesh arrays missing");
+        if (m.n_triangles >= (1u << 27)) return fail(RT_E_UNSUPPORTED, "mesh too large for leaf encoding");
+        for (uint32_t i = 0; i < m.n_triangles * 3; i++) {
+            if (m.tri_pos[i] >= m.n_positions || m.tri_nrm[i] >= m.n_normals) return fail(RT_E_INVALID, "triangle index out of range");
+            if (m.tri_uv && m.tri_uv[i] >= 0 && (uint32_t(m.tri_uv[i]) >= m.n_uvs || !m.uvs)) return fail(RT_E_INVALID, "uv index out of range");
+        }
+        BvhBuild bvh = build_bvh(m.positions, m.tri_pos, m.n_triangles, 4);
+        *node_base = uint32_t(out.nodes.size());
+        *tri_base = uint32_t(out.tris.size());
+        *depth = bvh.max_depth;
+        out.nodes.insert(out.nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
+        for (uint32_t slot = 0; slot < m.n_triangles; slot++) {
+            uint32_t t = bvh.tri_order[slot];
+            const double* p0 = m.positions + 3 * size_t(m.tri_pos[3 * size_t(t)]);
+            const double* p1 = m.positions + 3 * size_t(m.tri_pos[3 * size_t(t) + 1]);
+            const double* p2 = m.positions + 3 * size_t(m.tri_pos[3 * size_t(t) + 2]);
+            TriRec<double> r{};
+            for (int a = 0; a < 3; a++) {
+                r.v0[a] = p0[a];
+                r.e1[a] = p1[a] - p0[a];  // mesh.rs:69
+                r.e2[a] = p2[a] - p0[a];  // mesh.rs:70
+            }
+            out.tris.push_back(r);
+            TriAttr<double> at{};
+            const double* n0 = m.normals + 3 * size_t(m.tri_nrm[3 * size_t(t)]);
+            const double* n1 = m.normals + 3 * size_t(m.tri_nrm[3 * size_t(t) + 1]);
+            const double* n2 = m.normals + 3 * size_t(m.tri_nrm[3 * size_t(t) + 2]);
+            for (int a = 0; a < 3; a++) { at.n0[a] = n0[a]; at.n1[a] = n1[a]; at.n2[a] = n2[a]; }
+            bool has_uv = m.tri_uv && m.tri_uv[3 * size_t(t)] >= 0 && m.tri_uv[3 * size_t(t) + 1] >= 0 && m.tri_uv[3 * size_t(t) + 2] >= 0;
+            at.has_uv = has_uv ? 1 : 0;
+            if (has_uv) {
+                const double* a0 = m.uvs + 3 * size_t(m.tri_uv[3 * size_t(t)]);
+                const double* a1 = m.uvs + 3 * size_t(m.tri_uv[3 * size_t(t) + 1]);
+                const double* a2 = m.uvs + 3 * size_t(m.tri_uv[3 * size_t(t) + 2]);
+                at.uv0[0] = a0[0]; at.uv0[1] = a0[1];
+                at.uv1[0] = a1[0]; at.uv1[1] = a1[1];
+                at.uv2[0] = a2[0]; at.uv2[1] = a2[1];
+            }
+            out.attrs.push_back(at);
+        }
+        mesh_geometry[mi] = {*node_base, *tri_base};
+        mesh_depth[mi] = bvh.max_depth;
+        if (bvh.max_depth > out.max_bvh_depth) out.max_bvh_depth = bvh.max_depth;
+        return true;
+    }
+
+    bool compile_node(uint32_t node, int depth) {
+        if (status != RT_OK) return false;
+        if (node >= d.n_nodes) return fail(RT_E_INVALID, "node index out of range");
+        if (depth > 512) return fail(RT_E_INVALID, "Hit tree too deep (cycle?)");
+        const RtNode& n = d.nodes[node];
+        if (uint64_t(n.first_child) + n.n_children > d.n_child_indices) return fail(RT_E_INVALID, "child range out of bounds");
+        const uint32_t* kids = d.child_indices + n.first_child;
+        switch (n.type) {
+            case RT_NODE_SPHERE: {
+                int32_t i = sphere_index(node);
+                if (i < 0) return false;
+                emit(OP_SPHERE, i);
+                return true;
+            }
+            case RT_NODE_PLANE: {
+                int32_t i = plane_index(node);
+                if (i < 0) return false;
+                emit(OP_PLANE, i);
+                return true;
+            }
+            case RT_NODE_SKY:
+                if (!check_material(n.material)) return false;
+                emit(OP_SKY, n.material);
+                return true;
+            case RT_NODE_SUN: {
+                int32_t i = sun_index(node);
+                if (i < 0) return false;
+                emit(OP_SUN, i);
+                return true;
+            }
+            case RT_NODE_MESH: {
+                if (n.mesh < 0 || uint32_t(n.mesh) >= d.n_meshes) return fail(RT_E_INVALID, "mesh index out of range");
+                if (!check_material(n.material)) return false;
+                MeshInst mi{};
+                if (!mesh_geometry_for(n.mesh, &mi.node_base, &mi.tri_base, &mi.max_depth)) return false;
+                mi.material = n.material;
+                mi.flags = d.meshes[n.mesh].flags & (RT_MESH_FLAT_SHADING | RT_MESH_HIT_BACK_FACES);
+                if (d.meshes[n.mesh].tri_uv) mi.flags |= MESH_HAS_UV;
+                mi.n_tris = d.meshes[n.mesh].n_triangles;
+                out.meshes.push_back(mi);
+                emit(OP_MESH, int32_t(out.meshes.size()) - 1);
+                return true;
+            }
+            case RT_NODE_LIST:
+            case RT_NODE_BVH: {
+                if (n.type == RT_NODE_BVH && n.n_children != 2) return fail(RT_E_INVALID, "bvh node needs two children");
+                size_t bounds_op = SIZE_MAX;
+                bool check = n.type == RT_NODE_BVH || !(n.flags & RT_LIST_DISABLE_BOUNDS_CHECK);
+                if (check) {
+                    Bounds<double> b;
+                    for (int a = 0; a < 3; a++) { b.lo[a] = n.bounds[a]; b.hi[a] = n.bounds[3 + a]; }
+                    out.bounds.push_back(b);
+                    bounds_op = out.ops.size();
+                    emit(OP_BOUNDS, int32_t(out.bounds.size()) - 1);
+                }
+                for (uint32_t k = 0; k < n.n_children; k++)
+                    if (!compile_node(kids[k], depth + 1)) return false;
+                if (check) out.ops[bounds_op].skip = int32_t(out.ops.size());
+                return true;
+            }
+            case RT_NODE_TRANSFORM: {
+                if (n.n_children != 1) return fail(RT_E_INVALID, "transform node needs one child");
+                int32_t x = xform_index(n.transform);
+                if (x < 0) return false;
+                emit(OP_XFORM_PUSH, x);
+                chain.push_back(x);
+                bool ok = compile_node(kids[0], depth + 1);
+                chain.pop_back();
+                if (!ok) return false;
+                emit(OP_XFORM_POP, x);  // chain of the POP = the parent's chain
+                return true;
+            }
+            case RT_NODE_NULL:
+                return true;  // NullObject::test never hits (null_obj.rs:17)
+            case RT_NODE_VOLUME:
+                return fail(RT_E_UNSUPPORTED, "volume objects are not supported by the HIP kernels yet");
+            default:
+                return fail(RT_E_INVALID, "unknown node type");
+        }
+    }
+
+    bool texture_ok(int32_t t, int depth, bool* needs_uv) {
+        if (t < 0 || uint32_t(t) >= d.n_textures) return fail(RT_E_INVALID, "texture index out of range");
+        if (depth > 64) return fail(RT_E_INVALID, "texture graph too deep (cycle?)");
+        const RtTexture& tx = d.textures[t];
+        switch (tx.type) {
+            case RT_TEX_CONST_COLOR:
+            case RT_TEX_CONST_FLOAT:
+                return true;
+            case RT_TEX_UV_DEBUG:
+                *needs_uv = true;
+                return true;
+            case RT_TEX_CHECKER:
+                *needs_uv = true;
+                return texture_ok(tx.a, depth + 1, needs_uv) && texture_ok(tx.b, depth + 1, needs_uv);
+            case RT_TEX_CHECKER_SOLID:
+                return texture_ok(tx.a, depth + 1, needs_uv) && texture_ok(tx.b, depth + 1, needs_uv);
+            default:
+                return fail(RT_E_UNSUPPORTED, "texture type not supported by the HIP kernels yet (lerp/image/noise/channel)");
+        }
+    }
+
+    bool compile_tables() {
+        out.textures.resize(d.n_textures);
+        for (uint32_t i = 0; i < d.n_textures; i++) {
+            const RtTexture& t = d.textures[i];
+            TextureRec<double> r{};
+            r.type = int32_t(t.type);
+            r.a = t.a; r.b = t.b; r.c = t.c;
+            r.v[0] = t.v[0]; r.v[1] = t.v[1]; r.v[2] = t.v[2];
+            r.scale = t.scale;
+            out.textures[i] = r;
+        }
+        out.materials.resize(d.n_materials);
+        out.material_params.resize(d.n_materials);
+        for (uint32_t i = 0; i < d.n_materials; i++) {
+            const RtMaterial& m = d.materials[i];
+            MaterialRec r{};
+            r.type = int32_t(m.type);
+            r.tex_a = m.tex_a; r.tex_b = m.tex_b; r.tex_c = m.tex_c;
+            bool needs_uv = false;
+            switch (m.type) {
+                case RT_MAT_LAMBERTIAN: case RT_MAT_EMISSIVE: case RT_MAT_ISOTROPIC:
+                    if (!texture_ok(m.tex_a, 0, &needs_uv)) return false;
+                    break;
+                case RT_MAT_METAL:
+                    if (!texture_ok(m.tex_a, 0, &needs_uv) || !texture_ok(m.tex_b, 0, &needs_uv)) return false;
+                    break;
+                case RT_MAT_GLOSSY:
+                    if (!texture_ok(m.tex_a, 0, &needs_uv) || !texture_ok(m.tex_b, 0, &needs_uv)) return false;
+                    if (m.tex_c >= 0) return fail(RT_E_UNSUPPORTED, "normal-mapped glossy is not supported by the HIP kernels yet");
+                    break;
+                case RT_MAT_DIELECTRIC:
+                    break;
+                case RT_MAT_NORMAL_DEBUG:
+                    if (m.tex_c >= 0) return fail(RT_E_UNSUPPORTED, "normal-mapped normal_debug is not supported by the HIP kernels yet");
+                    break;
+                default:
+                    return fail(RT_E_INVALID, "unknown material type");
+            }
+            r.needs_uv = needs_uv ? 1 : 0;
+            out.materials[i] = r;
+            out.material_params[i].ior = m.ior;
+            out.material_params[i].inv_ior = 1.0 / m.ior;  // glossy.rs:30
+        }
+        return true;
+    }
+
+    bool add_light(uint32_t node) {
+        if (node >= d.n_nodes) return fail(RT_E_INVALID, "light node index out of range");
+        const RtNode& n = d.nodes[node];
+        LightRec l{LIGHT_OTHER, 0};
+        switch (n.type) {
+            case RT_NODE_PLANE: l.kind = LIGHT_PLANE; l.index = plane_index(node); break;
+            case RT_NODE_SPHERE: l.kind = LIGHT_SPHERE; l.index = sphere_index(node); break;
+            case RT_NODE_SKY: l.kind = LIGHT_SKY; break;
+            case RT_NODE_SUN: l.kind = LIGHT_SUN; l.index = sun_index(node); break;
+            case RT_NODE_LIST:
+                return fail(RT_E_UNSUPPORTED, "nested lists inside `lights` are not supported by the HIP kernels yet");
+            default: break;  // Transform / mesh / bvh / volume / null: pdf_value 0, random (1,0,0)
+        }
+        if (l.index < 0) return false;
+        out.lights.push_back(l);
+        return true;
+    }
+
+    bool compile_lights() {
+        if (d.lights_root >= d.n_nodes) return fail(RT_E_INVALID, "lights root out of range");
+        const RtNode& n = d.nodes[d.lights_root];
+        if (n.type == RT_NODE_LIST) {
+            out.lights_is_list = 1;
+            if (uint64_t(n.first_child) + n.n_children > d.n_child_indices) return fail(RT_E_INVALID, "child range out of bounds");
+            for (uint32_t k = 0; k < n.n_children; k++)
+                if (!add_light(d.child_indices[n.first_child + k])) return false;
+            return true;
+        }
+        out.lights_is_list = 0;
+        return add_light(d.lights_root);
+    }
+};
+
+}  // namespace
+
+int compile_scene(const RtSceneDesc* desc, CompiledScene* out, std::string* err) {
+    if (!desc || desc->abi_version != RT_MI355_ABI_VERSION) {
+        *err = "scene description missing or ABI version mismatch";
+        return RT_E_INVALID;
+    }
+    if ((desc->n_nodes && !desc->nodes) || (desc->n_child_indices && !desc->child_indices) ||
+        (desc->n_transforms && !desc->transforms) || (desc->n_meshes && !desc->meshes) ||
+        (desc->n_materials && !desc->materials) || (desc->n_textures && !desc->textures)) {
+        *err = "scene description has NULL tables";
+        return RT_E_INVALID;
+    }
+    *out = CompiledScene{};
+    Compiler c{*desc, *out, err};
+    if (!c.compile_tables()) return c.status;
+    if (!c.compile_node(desc->world_root, 0)) return c.status;
+    c.chain.clear();
+    out->ops.push_back({OP_END, 0, 0, c.chain_id()});
+    if (!c.compile_lights()) return c.status;
+    out->chain_offsets.push_back(0);
+    for (auto& ch : c.chains) {
+        out->chain_items.insert(out->chain_items.end(), ch.begin(), ch.end());
+        out->chain_offsets.push_back(int32_t(out->chain_items.size()));
+    }
+    return RT_OK;
+}
+
+}  // namespace rt

@@ -1,0 +1,36 @@
+// rt_compile.h — RtSceneDesc (tree of Hit nodes) -> flat host tables in f64, ready to be
+// rounded to the kernel's arithmetic type and uploaded.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/rt_mi355.h"
+#include "rt_bvh.h"
+#include "rt_scene.h"
+
+namespace rt {
+
+struct CompiledScene {
+    std::vector<Op> ops;
+    std::vector<Bounds<double>> bounds;
+    std::vector<int32_t> chain_offsets, chain_items;
+    std::vector<Xform<double>> xforms;
+    std::vector<SpherePrim<double>> spheres;
+    std::vector<PlanePrim<double>> planes;
+    std::vector<SunPrim<double>> suns;
+    std::vector<MeshInst> meshes;
+    std::vector<BuildNode> nodes;            // all meshes, node indices relative to MeshInst::node_base
+    std::vector<TriRec<double>> tris;        // leaf order
+    std::vector<TriAttr<double>> attrs;      // same order
+    std::vector<MaterialRec> materials;
+    std::vector<MaterialParams<double>> material_params;
+    std::vector<TextureRec<double>> textures;
+    std::vector<LightRec> lights;
+    int32_t lights_is_list = 0;
+    uint32_t max_bvh_depth = 1;
+};
+
+// Returns RT_OK or a negative RtStatus with `err` set.
+int compile_scene(const RtSceneDesc* desc, CompiledScene* out, std::string* err);
+
+}  // namespace rt

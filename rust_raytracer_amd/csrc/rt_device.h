@@ -1,0 +1,749 @@
+// rt_device.h — device functions of the render path, templated on the arithmetic type R
+// (double = the reference's precision, float = fast mode).  Hand-written for gfx950:
+// 64-lane waves, per-lane BVH stack in LDS, no CUDA compatibility layer.
+//
+// Every function cites the reference code it restates.  Arithmetic is written in the
+// reference's operation order; no fast-math, IEEE semantics for inf/NaN are relied upon
+// exactly like the Rust code does (e.g. 1/0 = inf in Ray::new, src/ray.rs:20).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#include "../../include/rt_mi355.h"
+#include "rt_scene.h"
+
+namespace rt {
+
+#define RT_DEV __device__ __forceinline__
+
+template <typename R> struct Lim;
+template <> struct Lim<double> {
+    static RT_DEV double inf() { return __builtin_huge_val(); }
+    static RT_DEV double max() { return DBL_MAX; }
+    static RT_DEV double eps() { return DBL_EPSILON; }  // f64::EPSILON (mesh.rs:77, plane.rs:74)
+};
+template <> struct Lim<float> {
+    static RT_DEV float inf() { return __builtin_huge_valf(); }
+    static RT_DEV float max() { return FLT_MAX; }
+    static RT_DEV float eps() { return FLT_EPSILON; }
+};
+
+template <typename R> RT_DEV R pi() { return R(3.14159265358979323846264338327950288); }
+
+// ------------------------------------------------------------------ vec4.rs (xyz part)
+template <typename R>
+struct V3 {
+    R x, y, z;
+};
+template <typename R> RT_DEV V3<R> mk(R x, R y, R z) { return {x, y, z}; }
+template <typename R> RT_DEV V3<R> ld3(const R* p) { return {p[0], p[1], p[2]}; }
+template <typename R> RT_DEV V3<R> operator+(V3<R> a, V3<R> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename R> RT_DEV V3<R> operator-(V3<R> a, V3<R> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename R> RT_DEV V3<R> operator*(V3<R> a, V3<R> b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+template <typename R> RT_DEV V3<R> operator*(V3<R> a, R s) { return {a.x * s, a.y * s, a.z * s}; }
+template <typename R> RT_DEV V3<R> operator/(V3<R> a, R s) { return {a.x / s, a.y / s, a.z / s}; }
+template <typename R> RT_DEV V3<R> operator-(V3<R> a) { return {-a.x, -a.y, -a.z}; }
+template <typename R> RT_DEV R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }   // vec4.rs:109
+template <typename R> RT_DEV R length_squared(V3<R> a) { return a.x * a.x + a.y * a.y + a.z * a.z; }  // vec4.rs:105
+template <typename R> RT_DEV R length(V3<R> a) { return sqrt(length_squared(a)); }                    // vec4.rs:101
+template <typename R> RT_DEV V3<R> cross(V3<R> a, V3<R> b) {                                          // vec4.rs:113
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <typename R> RT_DEV V3<R> to_unit(V3<R> a) { return a / length(a); }                         // vec4.rs:122
+template <typename R> RT_DEV V3<R> reflect(V3<R> v, V3<R> n) { return v - n * (R(2) * dot(v, n)); }   // vec4.rs:135
+template <typename R> RT_DEV V3<R> refract(V3<R> v, V3<R> n, R ior_ratio) {                           // vec4.rs:140-147
+    R cos_theta = fmin(R(1), dot(-v, n));
+    V3<R> perp = (v + (n * cos_theta)) * ior_ratio;
+    V3<R> parallel = n * -sqrt(R(1) - length_squared(perp));
+    return perp + parallel;
+}
+
+// Mat4 * Vec4 for affine matrices (mat4.rs:342-353); w = 1 for points, 0 for directions.
+// The `m3 * w` term is kept even for w = 0 so that signed zeros come out as in the reference.
+template <typename R> RT_DEV V3<R> xform_apply(const R* m, V3<R> v, R w) {
+    return {m[0] * v.x + m[1] * v.y + m[2] * v.z + m[3] * w,
+            m[4] * v.x + m[5] * v.y + m[6] * v.z + m[7] * w,
+            m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11] * w};
+}
+// from_columns(u, v, w, (0,0,0,1)) * vec(x, y, z) (mat4.rs:37-44, 342-353)
+template <typename R> RT_DEV V3<R> basis_apply(V3<R> u, V3<R> v, V3<R> w, V3<R> r) {
+    const R z = R(0);
+    return {u.x * r.x + v.x * r.y + w.x * r.z + z * z,
+            u.y * r.x + v.y * r.y + w.y * r.z + z * z,
+            u.z * r.x + v.z * r.y + w.z * r.z + z * z};
+}
+
+// utils.rs:17-28
+template <typename R> RT_DEV void onb_from_vec(V3<R> w, V3<R>& u, V3<R>& v) {
+    V3<R> a = fabs(w.x) > R(0.9) ? mk<R>(0, 1, 0) : mk<R>(1, 0, 0);
+    v = to_unit(cross(w, a));
+    u = cross(w, v);
+}
+// utils.rs:31-36 (powi(5) = x2 = x*x; x4 = x2*x2; x4*x)
+template <typename R> RT_DEV R reflectance(R cos_theta, R ior_ratio) {
+    R r0 = (R(1) - ior_ratio) / (R(1) + ior_ratio);
+    r0 = r0 * r0;
+    R x = R(1) - cos_theta;
+    R x2 = x * x;
+    R x4 = x2 * x2;
+    return r0 + (R(1) - r0) * (x4 * x);
+}
+
+// ------------------------------------------------------------------ RNG (DESIGN.md "RNG")
+// Keyed SplitMix64 stream: one stream per (seed, replica, pixel, stratum); draw order follows
+// SURVEY Appendix A.  Identical to oracle/oracle.cpp `struct Rng`.
+struct Rng {
+    uint64_t s;
+    static RT_DEV uint64_t mix(uint64_t z) {
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    RT_DEV void key(uint64_t seed, uint32_t tid, uint64_t pixel, uint32_t stratum) {
+        uint64_t k = mix(seed + 0x9E3779B97F4A7C15ull * (uint64_t(tid) + 1));
+        k = mix(k ^ (pixel * 0xD1B54A32D192ED03ull + 0x8CB92BA72F3D8DD7ull));
+        k = mix(k ^ (uint64_t(stratum) * 0xA0761D6478BD642Full + 0xE7037ED1A0B428DBull));
+        s = k;
+    }
+    RT_DEV uint64_t next() {
+        s += 0x9E3779B97F4A7C15ull;
+        return mix(s);
+    }
+    RT_DEV uint32_t below(uint32_t n) { return uint32_t(((next() >> 32) * uint64_t(n)) >> 32); }
+};
+template <typename R> RT_DEV R rng_uniform(Rng& g);
+template <> RT_DEV double rng_uniform<double>(Rng& g) { return double(g.next() >> 11) * (1.0 / 9007199254740992.0); }
+template <> RT_DEV float rng_uniform<float>(Rng& g) { return float(g.next() >> 40) * (1.0f / 16777216.0f); }
+template <typename R> RT_DEV R rng_normal(Rng& g) {  // Box-Muller, cosine branch
+    R u1 = rng_uniform<R>(g);
+    R u2 = rng_uniform<R>(g);
+    R r = sqrt(R(-2) * log(R(1) - u1));
+    return r * cos(R(2) * pi<R>() * u2);
+}
+template <typename R> RT_DEV V3<R> random_unit(Rng& g) {  // vec4.rs:42-48
+    R x = rng_normal<R>(g);
+    R y = rng_normal<R>(g);
+    R z = rng_normal<R>(g);
+    return to_unit(mk<R>(x, y, z));
+}
+template <typename R> RT_DEV V3<R> random_cosine(Rng& g) {  // vec4.rs:50-61
+    R r1 = rng_uniform<R>(g);
+    R r2 = rng_uniform<R>(g);
+    R phi = r1 * R(2) * pi<R>();
+    R sqrt_r2 = sqrt(r2);
+    R x = cos(phi) * sqrt_r2;
+    R y = sin(phi) * sqrt_r2;
+    R z = sqrt(R(1) - r2);
+    return mk<R>(x, y, z);
+}
+
+// ------------------------------------------------------------------ ray.rs
+template <typename R>
+struct Ray {
+    V3<R> o, d, inv;
+};
+template <typename R> RT_DEV Ray<R> make_ray(V3<R> o, V3<R> d) {  // ray.rs:19-33
+    return {o, d, mk<R>(R(1) / d.x, R(1) / d.y, R(1) / d.z)};
+}
+template <typename R> RT_DEV V3<R> ray_at(const Ray<R>& r, R t) { return r.o + (r.d * t); }  // ray.rs:35
+
+// aabb.rs:50-87, Williams et al.; `sign[i] = inv_dir[i] < 0` (ray.rs:21-25)
+template <typename R> RT_DEV bool test_bounding_box(const Bounds<R>& b, const Ray<R>& ray, R t_lo, R t_hi) {
+    bool sx = ray.inv.x < R(0), sy = ray.inv.y < R(0), sz = ray.inv.z < R(0);
+    R t_min = ((sx ? b.hi[0] : b.lo[0]) - ray.o.x) * ray.inv.x;
+    R t_max = ((sx ? b.lo[0] : b.hi[0]) - ray.o.x) * ray.inv.x;
+    R ty_min = ((sy ? b.hi[1] : b.lo[1]) - ray.o.y) * ray.inv.y;
+    R ty_max = ((sy ? b.lo[1] : b.hi[1]) - ray.o.y) * ray.inv.y;
+    if ((t_min > ty_max) || (ty_min > t_max)) return false;
+    if (ty_min > t_min) t_min = ty_min;
+    if (ty_max < t_max) t_max = ty_max;
+    R tz_min = ((sz ? b.hi[2] : b.lo[2]) - ray.o.z) * ray.inv.z;
+    R tz_max = ((sz ? b.lo[2] : b.hi[2]) - ray.o.z) * ray.inv.z;
+    if ((t_min > tz_max) || (tz_min > t_max)) return false;
+    if (tz_min > t_min) t_min = tz_min;
+    if (tz_max < t_max) t_max = tz_max;
+    return t_min < t_hi && t_max > t_lo;
+}
+
+// ------------------------------------------------------------------ primitives
+// sphere.rs:40-62: nearest root in (t_lo, t_hi), un-normalised direction
+template <typename R> RT_DEV bool sphere_test(const SpherePrim<R>& s, const Ray<R>& ray, R t_lo, R t_hi, R& t_out) {
+    V3<R> center_diff = ray.o - ld3(s.center);
+    R a = length_squared(ray.d);
+    R half_b = dot(ray.d, center_diff);
+    R c = length_squared(center_diff) - s.radius * s.radius;
+    R discriminant = half_b * half_b - a * c;
+    if (discriminant < R(0)) return false;
+    R d_sqrt = sqrt(discriminant);
+    R root = (-half_b - d_sqrt) / a;
+    if (root <= t_lo || t_hi <= root) {
+        root = (-half_b + d_sqrt) / a;
+        if (root <= t_lo || t_hi <= root) return false;
+    }
+    t_out = root;
+    return true;
+}
+
+// plane.rs:66-89
+template <typename R> RT_DEV bool plane_test(const PlanePrim<R>& p, const Ray<R>& ray, R t_lo, R t_hi, R& t_out, R& u_out, R& v_out) {
+    V3<R> normal = ld3(p.normal);
+    R dot_ray_normal = dot(normal, ray.d);
+    R dd = p.backface ? fabs(dot_ray_normal) : -dot_ray_normal;
+    if (dd < Lim<R>::eps()) return false;
+    V3<R> corner = ld3(p.corner);
+    R hit_t = dot(normal, corner - ray.o) / dot_ray_normal;
+    if (hit_t <= t_lo || t_hi <= hit_t) return false;
+    V3<R> hit_pos = ray_at(ray, hit_t);
+    V3<R> local_pos = hit_pos - corner;
+    R u = dot(local_pos, ld3(p.inv_u));
+    R v = dot(local_pos, ld3(p.inv_v));
+    if (u < R(0) || u > R(1) || v < R(0) || v > R(1)) return false;
+    t_out = hit_t;
+    u_out = u;
+    v_out = v;
+    return true;
+}
+
+// ------------------------------------------------------------------ closest-hit state
+template <typename R>
+struct Best {
+    R t;          // closest_t so far (Interval max handed to every later test)
+    int32_t pc;   // op that produced it, -1 = none
+    int32_t tri;  // mesh hits: triangle slot (absolute index into tris/attrs)
+    R u, v;       // mesh: barycentrics; plane: (u, v)
+};
+
+struct LaneCounters {
+    uint32_t rays = 0, mesh_rays = 0, node_visits = 0, tri_tests = 0, prim_tests = 0;
+};
+
+// mesh.rs:62-107 Moeller-Trumbore with the reference's cull and interval rules
+template <typename R, bool STATS>
+RT_DEV void mesh_traverse(const SceneView<R>& sc, const MeshInst& mi, const Ray<R>& ray, R t_lo, Best<R>& best, int32_t pc,
+                          int* stack, int stride, LaneCounters& cnt) {
+    const BvhNode<R>* nodes = sc.nodes + mi.node_base;
+    const TriRec<R>* tris = sc.tris + mi.tri_base;
+    const bool hit_back = (mi.flags & RT_MESH_HIT_BACK_FACES) != 0;
+    // Slab tests as t = b * inv - o * inv (culling only, any conservative test is admissible).
+    // A zero direction component gives inv = +-inf and inf - inf = NaN in that form, so the
+    // inverse used HERE is clamped to a huge finite value: a ray parallel to a slab is then
+    // "inside forever" or "outside forever", which is exact.
+    const R big = sizeof(R) == 8 ? R(1e150) : R(1e18);
+    const V3<R> inv = {fabs(ray.inv.x) > big ? copysign(big, ray.inv.x) : ray.inv.x,
+                       fabs(ray.inv.y) > big ? copysign(big, ray.inv.y) : ray.inv.y,
+                       fabs(ray.inv.z) > big ? copysign(big, ray.inv.z) : ray.inv.z};
+    const V3<R> oi = ray.o * inv;
+    int sp = 0;
+    int32_t cur = 0;
+    if (STATS) cnt.mesh_rays++;
+    for (;;) {
+        if (cur >= 0) {
+            const BvhNode<R>& n = nodes[cur];
+            if (STATS) cnt.node_visits++;
+            R t0x = n.lo0[0] * inv.x - oi.x, t1x = n.hi0[0] * inv.x - oi.x;
+            R t0y = n.lo0[1] * inv.y - oi.y, t1y = n.hi0[1] * inv.y - oi.y;
+            R t0z = n.lo0[2] * inv.z - oi.z, t1z = n.hi0[2] * inv.z - oi.z;
+            R near0 = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmax(fmin(t0z, t1z), t_lo));
+            R far0 = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmin(fmax(t0z, t1z), best.t));
+            R s0x = n.lo1[0] * inv.x - oi.x, s1x = n.hi1[0] * inv.x - oi.x;
+            R s0y = n.lo1[1] * inv.y - oi.y, s1y = n.hi1[1] * inv.y - oi.y;
+            R s0z = n.lo1[2] * inv.z - oi.z, s1z = n.hi1[2] * inv.z - oi.z;
+            R near1 = fmax(fmax(fmin(s0x, s1x), fmin(s0y, s1y)), fmax(fmin(s0z, s1z), t_lo));
+            R far1 = fmin(fmin(fmax(s0x, s1x), fmax(s0y, s1y)), fmin(fmax(s0z, s1z), best.t));
+            int32_t c0 = n.c0, c1 = n.c1;
+            bool h0 = (near0 <= far0) && c0 != kEmptyChild;
+            bool h1 = (near1 <= far1) && c1 != kEmptyChild;
+            if (h0 && h1) {
+                bool first0 = near0 <= near1;
+                stack[sp * stride] = first0 ? c1 : c0;
+                sp++;
+                cur = first0 ? c0 : c1;
+                continue;
+            }
+            if (h0) { cur = c0; continue; }
+            if (h1) { cur = c1; continue; }
+        } else {
+            uint32_t code = uint32_t(~cur);
+            uint32_t first = code >> 3, count = (code & 7u) + 1u;
+            for (uint32_t i = 0; i < count; i++) {
+                const TriRec<R>& tr = tris[first + i];
+                if (STATS) cnt.tri_tests++;
+                V3<R> edge1 = ld3(tr.e1), edge2 = ld3(tr.e2);
+                V3<R> ray_x_edge2 = cross(ray.d, edge2);
+                R det = dot(edge1, ray_x_edge2);
+                R dd = hit_back ? fabs(det) : det;
+                if (dd < Lim<R>::eps()) continue;
+                R inv_det = R(1) / det;
+                V3<R> b = ray.o - ld3(tr.v0);
+                R u = dot(b, ray_x_edge2) * inv_det;
+                if (u < R(0) || u > R(1)) continue;
+                V3<R> b_x_edge1 = cross(b, edge1);
+                R v = dot(ray.d, b_x_edge1) * inv_det;
+                if (v < R(0) || u + v > R(1)) continue;
+                R t = dot(edge2, b_x_edge1) * inv_det;
+                if (t <= t_lo || best.t <= t) continue;
+                best.t = t;
+                best.pc = pc;
+                best.tri = int32_t(mi.tri_base + first + i);
+                best.u = u;
+                best.v = v;
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = stack[sp * stride];
+    }
+}
+
+// Ray in the space of `chain` (outermost transform first): Transform::test, transform.rs:124-127
+template <typename R> RT_DEV Ray<R> ray_in_chain(const SceneView<R>& sc, const Ray<R>& wray, int32_t chain) {
+    int32_t b = sc.chain_offsets[chain], e = sc.chain_offsets[chain + 1];
+    if (b == e) return wray;
+    V3<R> o = wray.o, d = wray.d;
+    for (int32_t i = b; i < e; i++) {
+        const Xform<R>& x = sc.xforms[sc.chain_items[i]];
+        o = xform_apply(x.inv, o, R(1));
+        d = xform_apply(x.inv, d, R(0));
+    }
+    return make_ray(o, d);
+}
+
+// world.test(ray, Interval(t_lo, inf)) — closest hit over the whole scene program.
+// Reproduces ObjectList::test (list.rs:58-74), BoundingVolumeHierarchyNode::test
+// (bvh.rs:84-101) and Transform::test (transform.rs:122-139): depth-first, fixed order,
+// every test sees the interval (t_lo, closest_t so far).
+template <typename R, bool STATS>
+RT_DEV void world_test(const SceneView<R>& sc, const Ray<R>& wray, R t_lo, Best<R>& best, int* stack, int stride, LaneCounters& cnt) {
+    best.t = Lim<R>::inf();
+    best.pc = -1;
+    best.tri = -1;
+    best.u = R(0);
+    best.v = R(0);
+    Ray<R> cur = wray;
+    int32_t pc = 0;
+    if (STATS) cnt.rays++;
+    for (;;) {
+        const Op op = sc.ops[pc];
+        if (op.type == OP_END) break;
+        switch (op.type) {
+            case OP_BOUNDS:
+                if (!test_bounding_box(sc.bounds[op.arg], cur, t_lo, best.t)) {
+                    pc = op.skip;
+                    continue;
+                }
+                break;
+            case OP_XFORM_PUSH: {
+                const Xform<R>& x = sc.xforms[op.arg];
+                cur = make_ray(xform_apply(x.inv, cur.o, R(1)), xform_apply(x.inv, cur.d, R(0)));
+                break;
+            }
+            case OP_XFORM_POP:
+                cur = ray_in_chain(sc, wray, op.chain);
+                break;
+            case OP_SPHERE: {
+                R t;
+                if (STATS) cnt.prim_tests++;
+                if (sphere_test(sc.spheres[op.arg], cur, t_lo, best.t, t)) {
+                    best.t = t;
+                    best.pc = pc;
+                }
+                break;
+            }
+            case OP_PLANE: {
+                R t, u, v;
+                if (STATS) cnt.prim_tests++;
+                if (plane_test(sc.planes[op.arg], cur, t_lo, best.t, t, u, v)) {
+                    best.t = t;
+                    best.pc = pc;
+                    best.u = u;
+                    best.v = v;
+                }
+                break;
+            }
+            case OP_MESH:
+                mesh_traverse<R, STATS>(sc, sc.meshes[op.arg], cur, t_lo, best, pc, stack, stride, cnt);
+                break;
+            case OP_SKY:  // sky.rs:28-33: hit at t = inf unless `inf > t.max`
+                if (STATS) cnt.prim_tests++;
+                if (!(Lim<R>::inf() > best.t)) {
+                    best.t = Lim<R>::inf();
+                    best.pc = pc;
+                }
+                break;
+            case OP_SUN: {  // sun.rs:33-43
+                if (STATS) cnt.prim_tests++;
+                const SunPrim<R>& s = sc.suns[op.arg];
+                V3<R> unit_dir = to_unit(cur.d);
+                if (!(fabs(dot(ld3(s.direction), unit_dir) - R(1)) > R(0.001)) && !(Lim<R>::max() >= best.t)) {
+                    best.t = Lim<R>::max();
+                    best.pc = pc;
+                }
+                break;
+            }
+            default:
+                break;
+        }
+        pc++;
+    }
+}
+
+// ------------------------------------------------------------------ HitRecord (object.rs:32-72)
+template <typename R>
+struct HitInfo {
+    V3<R> pos, normal;
+    R u, v;
+    int32_t material;
+    bool front_face;
+};
+
+template <typename R>
+RT_DEV HitInfo<R> resolve_hit(const SceneView<R>& sc, const Ray<R>& wray, const Best<R>& best) {
+    const Op op = sc.ops[best.pc];
+    const Ray<R> ray = ray_in_chain(sc, wray, op.chain);
+    HitInfo<R> h;
+    V3<R> outward;
+    h.u = R(0);
+    h.v = R(0);
+    switch (op.type) {
+        case OP_SPHERE: {  // sphere.rs:64-93
+            const SpherePrim<R>& s = sc.spheres[op.arg];
+            h.pos = ray_at(ray, best.t);
+            outward = (h.pos - ld3(s.center)) / s.radius;
+            h.material = s.material;
+            if (sc.materials[s.material].needs_uv) {
+                R theta = acos(outward.y);
+                R phi = atan2(-outward.z, outward.x) + pi<R>();
+                h.u = phi / (R(2) * pi<R>());
+                h.v = theta / pi<R>();
+            }
+            break;
+        }
+        case OP_PLANE: {  // plane.rs:81-100
+            const PlanePrim<R>& p = sc.planes[op.arg];
+            h.pos = ray_at(ray, best.t);
+            outward = ld3(p.normal);
+            h.material = p.material;
+            h.u = best.u;
+            h.v = best.v;
+            break;
+        }
+        case OP_MESH: {  // mesh.rs:103-162
+            const MeshInst& mi = sc.meshes[op.arg];
+            const TriAttr<R>& at = sc.attrs[best.tri];
+            h.pos = ray_at(ray, best.t);
+            R w = R(1) - best.u - best.v;
+            if (mi.flags & RT_MESH_FLAT_SHADING) {
+                const TriRec<R>& tr = sc.tris[best.tri];
+                outward = to_unit(cross(ld3(tr.e1), ld3(tr.e2)));
+            } else {
+                outward = ld3(at.n0) * w + ld3(at.n1) * best.u + ld3(at.n2) * best.v;  // not normalised (SURVEY B-4)
+            }
+            if (at.has_uv) {
+                h.u = at.uv0[0] * w + at.uv1[0] * best.u + at.uv2[0] * best.v;
+                h.v = at.uv0[1] * w + at.uv1[1] * best.u + at.uv2[1] * best.v;
+            }
+            h.material = mi.material;
+            break;
+        }
+        case OP_SKY: {  // sky.rs:35-51
+            h.pos = ray_at(ray, Lim<R>::inf());
+            V3<R> unit_dir = to_unit(ray.d);
+            outward = -unit_dir;
+            h.material = op.arg;
+            if (sc.materials[op.arg].needs_uv) {
+                h.u = atan2(unit_dir.x, unit_dir.z) / (R(2) * pi<R>()) + R(0.5);
+                h.v = dot(unit_dir, mk<R>(0, 1, 0)) / R(2) + R(0.5);
+            }
+            break;
+        }
+        default: {  // OP_SUN, sun.rs:45-60
+            const SunPrim<R>& s = sc.suns[op.arg];
+            h.pos = ray_at(ray, Lim<R>::max());
+            outward = -to_unit(ray.d);
+            h.material = s.material;
+            break;
+        }
+    }
+    h.front_face = dot(ray.d, outward) < R(0);  // object.rs:55, decided in object space
+    h.normal = h.front_face ? outward : -outward;
+    // Transform::test on the way back up (transform.rs:132-133), innermost first
+    int32_t b = sc.chain_offsets[op.chain], e = sc.chain_offsets[op.chain + 1];
+    for (int32_t i = e - 1; i >= b; i--) {
+        const Xform<R>& x = sc.xforms[sc.chain_items[i]];
+        h.pos = xform_apply(x.m, h.pos, R(1));
+        h.normal = to_unit(xform_apply(x.m, h.normal, R(0)));
+    }
+    return h;
+}
+
+// ------------------------------------------------------------------ textures (texture/*.rs)
+template <typename R> RT_DEV uint32_t as_u32_sat(R x) {  // Rust `as u32`
+    if (!(x > R(0))) return 0u;
+    if (x >= R(4294967295.0)) return 4294967295u;
+    return uint32_t(x);
+}
+template <typename R> RT_DEV int32_t as_i32_sat(R x) {
+    if (x != x) return 0;
+    if (x <= R(-2147483648.0)) return INT32_MIN;
+    if (x >= R(2147483647.0)) return INT32_MAX;
+    return int32_t(x);
+}
+// Walks checker nodes down to a leaf texture (checkerboard.rs:34-44, 74-85).
+template <typename R> RT_DEV int32_t texture_leaf(const SceneView<R>& sc, int32_t t, R u, R v, V3<R> p) {
+    for (;;) {
+        const TextureRec<R>& tx = sc.textures[t];
+        if (tx.type == RT_TEX_CHECKER) {
+            uint32_t iu = as_u32_sat(u * R(2) / tx.scale);
+            uint32_t iv = as_u32_sat(v * R(2) / tx.scale);
+            t = ((iu + iv) % 2u) == 0u ? tx.a : tx.b;
+        } else if (tx.type == RT_TEX_CHECKER_SOLID) {
+            int32_t ix = as_i32_sat(floor(p.x / tx.scale));
+            int32_t iy = as_i32_sat(floor(p.y / tx.scale));
+            int32_t iz = as_i32_sat(floor(p.z / tx.scale));
+            int32_t s = int32_t(uint32_t(ix) + uint32_t(iy) + uint32_t(iz));
+            t = (s % 2) == 0 ? tx.a : tx.b;
+        } else {
+            return t;
+        }
+    }
+}
+template <typename R> RT_DEV V3<R> sample_color(const SceneView<R>& sc, int32_t t, const HitInfo<R>& h) {
+    const TextureRec<R>& tx = sc.textures[texture_leaf(sc, t, h.u, h.v, h.pos)];
+    if (tx.type == RT_TEX_UV_DEBUG) return mk<R>(h.u, h.v, R(0.5));  // uv_debug.rs:11-13
+    return ld3(tx.v);                                                // constant.rs:30
+}
+template <typename R> RT_DEV R sample_float(const SceneView<R>& sc, int32_t t, const HitInfo<R>& h) {
+    return sc.textures[texture_leaf(sc, t, h.u, h.v, h.pos)].v[0];
+}
+
+// ------------------------------------------------------------------ lights (pdf/hittable.rs + Hit::pdf_value / random)
+// plane.rs:107-118
+template <typename R, bool STATS> RT_DEV R plane_pdf_value(const PlanePrim<R>& p, V3<R> origin, V3<R> dir, LaneCounters& cnt) {
+    Ray<R> ray = make_ray(origin, dir);
+    R t, u, v;
+    if (STATS) cnt.prim_tests++;
+    if (plane_test(p, ray, R(0.001), Lim<R>::inf(), t, u, v)) {
+        V3<R> n = ld3(p.normal);
+        bool front = dot(dir, n) < R(0);
+        V3<R> hn = front ? n : -n;  // hit.normal() is the face-forwarded normal
+        R dist_squared = t * t * length_squared(dir);
+        R cosine = fabs(dot(dir, hn) / length(dir));
+        return dist_squared / (cosine * p.area);
+    }
+    return R(0);
+}
+// sphere.rs:106-121
+template <typename R, bool STATS> RT_DEV R sphere_pdf_value(const SpherePrim<R>& s, V3<R> origin, V3<R> dir, LaneCounters& cnt) {
+    Ray<R> ray = make_ray(origin, dir);
+    R t;
+    if (STATS) cnt.prim_tests++;
+    if (sphere_test(s, ray, R(0.001), Lim<R>::inf(), t)) {
+        R radius_squared = s.radius * s.radius;
+        R cos_theta_max = sqrt(R(1) - radius_squared / length_squared(ld3(s.center) - origin));
+        R solid_angle = R(2) * pi<R>() * (R(1) - cos_theta_max);
+        return R(1) / solid_angle;
+    }
+    return R(0);
+}
+template <typename R, bool STATS> RT_DEV R light_pdf_value(const SceneView<R>& sc, const LightRec& l, V3<R> origin, V3<R> dir, LaneCounters& cnt) {
+    switch (l.kind) {
+        case LIGHT_PLANE: return plane_pdf_value<R, STATS>(sc.planes[l.index], origin, dir, cnt);
+        case LIGHT_SPHERE: return sphere_pdf_value<R, STATS>(sc.spheres[l.index], origin, dir, cnt);
+        case LIGHT_SKY: return R(1) / (R(4) * pi<R>());  // sky.rs:61-63
+        case LIGHT_SUN: return R(1);                      // sun.rs:70-72
+        default: return R(0);                             // Transform / mesh / bvh / volume
+    }
+}
+// lights.pdf_value(origin, dir): ObjectList (list.rs:80-89) or the single object
+template <typename R, bool STATS> RT_DEV R lights_pdf_value(const SceneView<R>& sc, V3<R> origin, V3<R> dir, LaneCounters& cnt) {
+    if (!sc.lights_is_list) return light_pdf_value<R, STATS>(sc, sc.lights[0], origin, dir, cnt);
+    R weight = R(1) / R(sc.n_lights);
+    R sum = R(0);
+    for (int32_t i = 0; i < sc.n_lights; i++) sum += weight * light_pdf_value<R, STATS>(sc, sc.lights[i], origin, dir, cnt);
+    return sum;
+}
+template <typename R> RT_DEV V3<R> light_random(const SceneView<R>& sc, const LightRec& l, V3<R> origin, Rng& rng) {
+    switch (l.kind) {
+        case LIGHT_PLANE: {  // plane.rs:120-126: corner + u*U + v*V covers one quarter (SURVEY B-1)
+            const PlanePrim<R>& p = sc.planes[l.index];
+            R ru = rng_uniform<R>(rng);
+            R rv = rng_uniform<R>(rng);
+            V3<R> pt = ld3(p.corner) + ld3(p.u) * ru + ld3(p.v) * rv;
+            return pt - origin;
+        }
+        case LIGHT_SPHERE: {  // sphere.rs:123-145
+            const SpherePrim<R>& s = sc.spheres[l.index];
+            V3<R> dir = ld3(s.center) - origin;
+            V3<R> bu, bv;
+            onb_from_vec(dir, bu, bv);
+            R radius_squared = s.radius * s.radius;
+            R cos_theta_max = sqrt(R(1) - radius_squared / length_squared(dir));
+            R r1 = rng_uniform<R>(rng);
+            R r2 = rng_uniform<R>(rng);
+            R phi = r1 * R(2) * pi<R>();
+            R z = R(1) + r2 * (cos_theta_max - R(1));
+            R x = cos(phi) * sqrt(R(1) - z * z);
+            R y = sin(phi) * sqrt(R(1) - z * z);
+            return basis_apply(bu, bv, dir, mk<R>(x, y, z));
+        }
+        case LIGHT_SKY: return random_unit<R>(rng);           // sky.rs:65-67
+        case LIGHT_SUN: return ld3(sc.suns[l.index].direction);  // sun.rs:74-76
+        default: return mk<R>(1, 0, 0);
+    }
+}
+template <typename R> RT_DEV V3<R> lights_random(const SceneView<R>& sc, V3<R> origin, Rng& rng) {
+    if (!sc.lights_is_list) return light_random(sc, sc.lights[0], origin, rng);
+    if (sc.n_lights == 0) return mk<R>(1, 0, 0);  // list.rs:93-95
+    uint32_t idx = rng.below(uint32_t(sc.n_lights));
+    return light_random(sc, sc.lights[idx], origin, rng);
+}
+
+// ------------------------------------------------------------------ camera.rs:260-280, 334-349
+template <typename R>
+RT_DEV Ray<R> get_ray(const CameraView<R>& cam, uint32_t px, uint32_t py, uint32_t sx, uint32_t sy, Rng& rng) {
+    V3<R> pdu = ld3(cam.pdu), pdv = ld3(cam.pdv);
+    V3<R> pixel_center = ld3(cam.first_pixel) + (pdu * R(px)) + (pdv * R(py));
+    R rx = rng_uniform<R>(rng);
+    R ry = rng_uniform<R>(rng);
+    R x = (R(sx) + rx) * cam.inv_sqrt_spt - R(0.5);
+    R y = (R(sy) + ry) * cam.inv_sqrt_spt - R(0.5);
+    V3<R> pixel_sample = pixel_center + (pdu * x + pdv * y);
+    V3<R> origin = ld3(cam.position);
+    if (cam.has_aperture) {
+        // random_in_unit_disk normalises a 2-D Gaussian: samples lie ON the unit circle (SURVEY B-2)
+        R dx = rng_normal<R>(rng);
+        R dy = rng_normal<R>(rng);
+        R len = sqrt(dx * dx + dy * dy + R(0) * R(0));
+        dx = dx / len;
+        dy = dy / len;
+        origin = origin + (ld3(cam.basis_u) * dx + ld3(cam.basis_v) * dy) * cam.aperture_radius;
+    }
+    return make_ray(origin, pixel_sample - origin);
+}
+
+// ------------------------------------------------------------------ one path vertex (camera.rs:282-332)
+// State of a path in the iterative form L = sum_k T_k E_k + T_end BG.
+template <typename R>
+struct PathState {
+    Ray<R> ray;
+    V3<R> throughput;
+    V3<R> radiance;
+    uint32_t depth;  // remaining depth, like the `depth` argument of ray_color
+};
+
+// Shades the closest hit; returns true if the path continues with ps.ray updated.
+template <typename R, bool STATS>
+RT_DEV bool shade(const SceneView<R>& sc, const ParamsView<R>& prm, PathState<R>& ps, const Best<R>& best, Rng& rng, LaneCounters& cnt) {
+    if (best.pc < 0) {  // camera.rs:331 background
+        ps.radiance = ps.radiance + ps.throughput * ld3(prm.background);
+        return false;
+    }
+    const HitInfo<R> hit = resolve_hit(sc, ps.ray, best);
+    const MaterialRec mat = sc.materials[hit.material];
+    V3<R> attenuation;
+    V3<R> pdf_w;          // CosinePDF::w (the shading normal), cosine.rs:17-22
+    bool with_pdf = false;
+    bool uniform_pdf = false;
+    switch (mat.type) {
+        case RT_MAT_EMISSIVE: {  // emissive.rs:24-34; camera.rs:327
+            if (hit.front_face) ps.radiance = ps.radiance + ps.throughput * sample_color(sc, mat.tex_a, hit);
+            return false;
+        }
+        case RT_MAT_NORMAL_DEBUG: {  // normal_debug.rs:42-48
+            ps.radiance = ps.radiance + ps.throughput * (hit.normal * R(0.5) + mk<R>(R(0.5), R(0.5), R(0.5)));
+            return false;
+        }
+        case RT_MAT_LAMBERTIAN:  // lambertian.rs:25-33
+            attenuation = sample_color(sc, mat.tex_a, hit);
+            pdf_w = hit.normal;
+            with_pdf = true;
+            break;
+        case RT_MAT_ISOTROPIC:  // isotropic.rs:25-33
+            attenuation = sample_color(sc, mat.tex_a, hit);
+            with_pdf = true;
+            uniform_pdf = true;
+            break;
+        case RT_MAT_METAL: {  // metal.rs:28-44
+            V3<R> reflected = reflect(ps.ray.d, hit.normal);
+            V3<R> scatter_dir = reflected + random_unit<R>(rng) * sample_float(sc, mat.tex_b, hit) * length(reflected);
+            if (!(dot(scatter_dir, hit.normal) > R(0))) return false;  // Absorbed (camera.rs:326)
+            ps.throughput = ps.throughput * sample_color(sc, mat.tex_a, hit);
+            ps.ray = make_ray(hit.pos, scatter_dir);
+            return true;
+        }
+        case RT_MAT_DIELECTRIC: {  // dielectric.rs:29-54
+            R ior = sc.material_params[hit.material].ior;
+            R ior_ratio = hit.front_face ? R(1) / ior : ior;
+            V3<R> unit_dir = to_unit(ps.ray.d);
+            R cos_theta = fmin(R(1), dot(-unit_dir, hit.normal));
+            R sin_theta = sqrt(R(1) - cos_theta * cos_theta);
+            bool tir = ior_ratio * sin_theta > R(1);
+            bool reflected = tir || reflectance(cos_theta, ior_ratio) > rng_uniform<R>(rng);  // no draw on TIR
+            V3<R> scatter_dir = reflected ? reflect(unit_dir, hit.normal) : refract(unit_dir, hit.normal, ior_ratio);
+            ps.ray = make_ray(hit.pos, scatter_dir);  // attenuation (1,1,1)
+            return true;
+        }
+        case RT_MAT_GLOSSY: {  // glossy.rs:54-83
+            V3<R> normal = hit.normal;
+            V3<R> unit_dir = to_unit(ps.ray.d);
+            R cos_theta = fmin(R(1), dot(-unit_dir, normal));
+            bool specular = reflectance(cos_theta, sc.material_params[hit.material].inv_ior) > rng_uniform<R>(rng);
+            if (specular) {
+                R roughness = sample_float(sc, mat.tex_b, hit);
+                V3<R> reflected = reflect(ps.ray.d, normal);
+                V3<R> scatter_dir = reflected + random_unit<R>(rng) * roughness * length(reflected);
+                if (!(dot(scatter_dir, normal) > R(0))) return false;  // Absorbed
+                ps.ray = make_ray(hit.pos, scatter_dir);               // attenuation (1,1,1)
+                return true;
+            }
+            attenuation = sample_color(sc, mat.tex_a, hit);
+            pdf_w = normal;
+            with_pdf = true;
+            break;
+        }
+        default:
+            return false;
+    }
+    if (!with_pdf) return false;
+
+    // ScatteredWithPDF: camera.rs:298-315 with MixPDF (mix.rs:23-36)
+    V3<R> dir;
+    if (rng_uniform<R>(rng) < prm.light_bias) {
+        dir = lights_random(sc, hit.pos, rng);
+    } else if (uniform_pdf) {
+        dir = random_unit<R>(rng);  // uniform.rs:22-24
+    } else {
+        V3<R> bu, bv;
+        onb_from_vec(pdf_w, bu, bv);
+        dir = basis_apply(bu, bv, pdf_w, random_cosine<R>(rng));  // cosine.rs:31-33
+    }
+    R first_val;
+    R scattering_pdf;
+    if (uniform_pdf) {
+        first_val = R(1) / (R(4) * pi<R>());       // uniform.rs:18-20
+        scattering_pdf = R(1) / (R(4) * pi<R>());  // isotropic.rs:35-37
+    } else {
+        V3<R> unit = to_unit(dir);
+        first_val = fmax(dot(unit, pdf_w) / pi<R>(), R(0));  // cosine.rs:26-29
+        R cos_theta = dot(pdf_w, unit);                      // lambertian.rs:35-43 / glossy.rs:86-95
+        scattering_pdf = cos_theta < R(0) ? R(0) : cos_theta / pi<R>();
+    }
+    R second_val = lights_pdf_value<R, STATS>(sc, hit.pos, dir, cnt);
+    R pdf = first_val * (R(1) - prm.light_bias) + second_val * prm.light_bias;
+    // (scatter_color * attenuation * scattering_pdf) / pdf, camera.rs:312
+    V3<R> w = (attenuation * scattering_pdf) / pdf;
+    ps.throughput = ps.throughput * w;
+    ps.ray = make_ray(hit.pos, dir);
+    // A weight of exactly zero multiplies everything the continuation could return: stop here.
+    if (w.x == R(0) && w.y == R(0) && w.z == R(0)) return false;
+    // 0/0 (scattering_pdf == 0 and pdf == 0, e.g. a light sample that misses every light and
+    // points below the surface): the reference's `(L * att * 0) / 0` is NaN whatever L is.
+    if (w.x != w.x || w.y != w.y || w.z != w.z) {
+        ps.radiance = ps.radiance + w;
+        return false;
+    }
+    return true;
+}
+
+}  // namespace rt

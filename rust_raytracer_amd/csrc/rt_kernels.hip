@@ -1,0 +1,558 @@
+// rt_kernels.hip — render kernels and the C ABI (include/rt_mi355.h) of librt_mi355.so.
+// gfx950 only: 64-lane waves, per-lane traversal stack in LDS, HIP events on the launch stream.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "rt_compile.h"
+#include "rt_device.h"
+
+namespace rt {
+
+// Packed owned row r -> image row y (RtRenderParams row partition).
+template <typename R> RT_DEV uint32_t row_to_y(const ParamsView<R>& prm, uint32_t r) {
+    if (prm.band_rows == 0 || prm.n_parts <= 1) return r;
+    uint32_t band = r / prm.band_rows;
+    return (band * prm.n_parts + prm.part) * prm.band_rows + (r % prm.band_rows);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Megakernel: one lane owns one pixel and walks its samples in the reference's order
+// (replica tid, then sy, sx: camera.rs:197,217-218), one bounce per loop trip.  A lane whose path
+// ended starts its next sample in the same trip, so the wave stays converged on
+// world_test -> shade and no lane idles while it still has samples.  Sums are accumulated
+// per pixel in the reference's order, so the result does not depend on scheduling.
+// ---------------------------------------------------------------------------------------------
+template <typename R, bool STATS>
+__global__ void __launch_bounds__(256) k_megakernel(SceneView<R> sc, CameraView<R> cam, ParamsView<R> prm,
+                                                    double* __restrict__ out, DeviceCounters* counters) {
+    extern __shared__ int lds_stack[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t tiles_x = (cam.width + 15u) / 16u;
+    const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const uint32_t px = bx * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t row = by * 16u + (wave >> 1) * 8u + (lane >> 3);
+    if (px >= cam.width || row >= prm.owned_rows) return;
+    const uint32_t py = row_to_y(prm, row);
+    int* stack = lds_stack + threadIdx.x;
+    const int stride = int(blockDim.x);
+
+    const uint32_t S = cam.sqrt_spt;
+    const uint32_t per_replica = S * S;
+    const uint32_t total = per_replica * cam.thread_count;
+    const uint64_t pixel_index = uint64_t(py) * cam.width + px;
+
+    LaneCounters cnt;
+    double acc[3] = {0.0, 0.0, 0.0};  // buf += thread_buf, camera.rs:247-253
+    double col[3] = {0.0, 0.0, 0.0};  // `color` of the current replica, camera.rs:215-229
+    uint32_t sample = 0;              // next sample to start
+    uint32_t in_replica = 0;
+    bool alive = false;
+    PathState<R> ps;
+    Rng rng;
+    rng.s = 0;
+
+    for (;;) {
+        if (!alive) {
+            if (sample == total) break;
+            uint32_t tid = sample / per_replica;
+            uint32_t st = sample - tid * per_replica;
+            uint32_t sy = st / S, sx = st - sy * S;
+            rng.key(prm.seed, tid, pixel_index, st);
+            ps.ray = get_ray(cam, px, py, sx, sy, rng);
+            ps.throughput = mk<R>(1, 1, 1);
+            ps.radiance = mk<R>(0, 0, 0);
+            ps.depth = cam.max_depth;
+            alive = true;
+            sample++;
+        }
+        bool cont = false;
+        if (ps.depth != 0) {  // camera.rs:290
+            Best<R> best;
+            world_test<R, STATS>(sc, ps.ray, R(0.001), best, stack, stride, cnt);
+            cont = shade<R, STATS>(sc, prm, ps, best, rng, cnt);
+            ps.depth--;
+        }
+        if (!cont) {
+            alive = false;
+            col[0] += double(ps.radiance.x);
+            col[1] += double(ps.radiance.y);
+            col[2] += double(ps.radiance.z);
+            if (++in_replica == per_replica) {
+                in_replica = 0;
+                for (int k = 0; k < 3; k++) {
+                    acc[k] += col[k] / prm.spp;  // color /= samples_per_pixel (total), camera.rs:229
+                    col[k] = 0.0;
+                }
+            }
+        }
+    }
+    double* o = out + (size_t(row) * cam.width + px) * 4;
+    o[0] = acc[0];
+    o[1] = acc[1];
+    o[2] = acc[2];
+    o[3] = 0.0;
+    if (STATS) {
+        atomicAdd(&counters->rays, (unsigned long long)cnt.rays);
+        atomicAdd(&counters->mesh_rays, (unsigned long long)cnt.mesh_rays);
+        atomicAdd(&counters->node_visits, (unsigned long long)cnt.node_visits);
+        atomicAdd(&counters->tri_tests, (unsigned long long)cnt.tri_tests);
+        atomicAdd(&counters->prim_tests, (unsigned long long)cnt.prim_tests);
+    }
+}
+
+// Diagnostic probe: one sample traced by one lane, with a per-bounce record
+// (t, pos xyz, material, op type, 0, 0).  Used by the parity tests to localise differences.
+template <typename R>
+__global__ void k_trace_sample(SceneView<R> sc, CameraView<R> cam, ParamsView<R> prm, uint32_t tid, uint32_t px, uint32_t py,
+                               uint32_t sx, uint32_t sy, double* rgb, double* trace, uint32_t max_bounces, uint32_t* n_out) {
+    extern __shared__ int lds_stack[];
+    if (threadIdx.x != 0) return;
+    LaneCounters cnt;
+    Rng rng;
+    rng.key(prm.seed, tid, uint64_t(py) * cam.width + px, sy * cam.sqrt_spt + sx);
+    PathState<R> ps;
+    ps.ray = get_ray(cam, px, py, sx, sy, rng);
+    ps.throughput = mk<R>(1, 1, 1);
+    ps.radiance = mk<R>(0, 0, 0);
+    ps.depth = cam.max_depth;
+    uint32_t n = 0;
+    while (ps.depth != 0) {
+        Best<R> best;
+        world_test<R, false>(sc, ps.ray, R(0.001), best, lds_stack, int(blockDim.x), cnt);
+        if (n < max_bounces) {
+            double* t = trace + 8 * n;
+            t[0] = double(best.t);
+            if (best.pc >= 0) {
+                HitInfo<R> h = resolve_hit(sc, ps.ray, best);
+                t[1] = double(h.pos.x); t[2] = double(h.pos.y); t[3] = double(h.pos.z);
+                t[4] = double(h.material);
+                t[5] = double(sc.ops[best.pc].type);
+                t[6] = double(h.normal.x); t[7] = double(h.normal.y);
+            } else {
+                t[1] = t[2] = t[3] = 0; t[4] = -1; t[5] = -1; t[6] = t[7] = 0;
+            }
+        }
+        n++;
+        bool cont = shade<R, false>(sc, prm, ps, best, rng, cnt);
+        ps.depth--;
+        if (!cont) break;
+    }
+    rgb[0] = double(ps.radiance.x); rgb[1] = double(ps.radiance.y); rgb[2] = double(ps.radiance.z);
+    *n_out = n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int set_err(int st, const std::string& msg) {
+    g_err = msg;
+    return st;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return set_err(RT_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+struct DeviceBuffers {
+    std::vector<void*> allocs;
+    ~DeviceBuffers() {
+        for (void* p : allocs) (void)hipFree(p);
+    }
+    template <typename T> int upload(const std::vector<T>& v, const T** out) {
+        *out = nullptr;
+        size_t bytes = (v.empty() ? 1 : v.size()) * sizeof(T);
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, bytes));
+        allocs.push_back(p);
+        if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        *out = static_cast<const T*>(p);
+        return RT_OK;
+    }
+};
+
+template <typename R> R round_down(double x);
+template <typename R> R round_up(double x);
+template <> double round_down<double>(double x) { return x; }
+template <> double round_up<double>(double x) { return x; }
+template <> float round_down<float>(double x) {
+    float f = float(x);
+    if (double(f) > x) f = nextafterf(f, -INFINITY);
+    return f;
+}
+template <> float round_up<float>(double x) {
+    float f = float(x);
+    if (double(f) < x) f = nextafterf(f, INFINITY);
+    return f;
+}
+
+template <typename R, size_t N> void cast_arr(R (&dst)[N], const double (&src)[N]) {
+    for (size_t i = 0; i < N; i++) dst[i] = R(src[i]);
+}
+
+// Scene tables in arithmetic type R on the device.
+template <typename R>
+struct DeviceScene {
+    DeviceBuffers buf;
+    SceneView<R> view{};
+
+    int build(const CompiledScene& cs) {
+        std::vector<Bounds<R>> bounds(cs.bounds.size());
+        for (size_t i = 0; i < bounds.size(); i++) {
+            // list/bvh bounds are part of the reference's semantics (inverted boxes cull, B-8): nearest rounding
+            cast_arr(bounds[i].lo, cs.bounds[i].lo);
+            cast_arr(bounds[i].hi, cs.bounds[i].hi);
+        }
+        std::vector<Xform<R>> xforms(cs.xforms.size());
+        for (size_t i = 0; i < xforms.size(); i++) {
+            cast_arr(xforms[i].m, cs.xforms[i].m);
+            cast_arr(xforms[i].inv, cs.xforms[i].inv);
+        }
+        std::vector<SpherePrim<R>> spheres(cs.spheres.size());
+        for (size_t i = 0; i < spheres.size(); i++) {
+            cast_arr(spheres[i].center, cs.spheres[i].center);
+            spheres[i].radius = R(cs.spheres[i].radius);
+            spheres[i].material = cs.spheres[i].material;
+            spheres[i]._pad = 0;
+        }
+        std::vector<PlanePrim<R>> planes(cs.planes.size());
+        for (size_t i = 0; i < planes.size(); i++) {
+            const auto& s = cs.planes[i];
+            cast_arr(planes[i].corner, s.corner); cast_arr(planes[i].normal, s.normal);
+            cast_arr(planes[i].u, s.u); cast_arr(planes[i].v, s.v);
+            cast_arr(planes[i].inv_u, s.inv_u); cast_arr(planes[i].inv_v, s.inv_v);
+            planes[i].area = R(s.area);
+            planes[i].material = s.material;
+            planes[i].backface = s.backface;
+        }
+        std::vector<SunPrim<R>> suns(cs.suns.size());
+        for (size_t i = 0; i < suns.size(); i++) {
+            cast_arr(suns[i].direction, cs.suns[i].direction);
+            suns[i].material = cs.suns[i].material;
+            suns[i]._pad = 0;
+        }
+        std::vector<BvhNode<R>> nodes(cs.nodes.size());
+        for (size_t i = 0; i < nodes.size(); i++) {
+            const BuildNode& s = cs.nodes[i];
+            BvhNode<R>& n = nodes[i];
+            // Conservative boxes: outward rounding plus a few ulps so that the slab arithmetic
+            // never culls a triangle the exact test would hit.
+            auto pad = [](double lo, double hi, R* olo, R* ohi) {
+                if (!(lo <= hi)) { *olo = R(lo); *ohi = R(hi); return; }  // empty child box
+                double m = std::fmax(std::fabs(lo), std::fabs(hi));
+                double e = 8.0 * double(std::numeric_limits<R>::epsilon()) * std::fmax(m, hi - lo);
+                *olo = round_down<R>(lo - e);
+                *ohi = round_up<R>(hi + e);
+            };
+            for (int a = 0; a < 3; a++) {
+                pad(s.lo0[a], s.hi0[a], &n.lo0[a], &n.hi0[a]);
+                pad(s.lo1[a], s.hi1[a], &n.lo1[a], &n.hi1[a]);
+            }
+            n.c0 = s.c0;
+            n.c1 = s.c1;
+        }
+        std::vector<TriRec<R>> tris(cs.tris.size());
+        for (size_t i = 0; i < tris.size(); i++) {
+            cast_arr(tris[i].v0, cs.tris[i].v0); cast_arr(tris[i].e1, cs.tris[i].e1); cast_arr(tris[i].e2, cs.tris[i].e2);
+            tris[i]._pad = R(0);
+        }
+        std::vector<TriAttr<R>> attrs(cs.attrs.size());
+        for (size_t i = 0; i < attrs.size(); i++) {
+            const auto& s = cs.attrs[i];
+            cast_arr(attrs[i].n0, s.n0); cast_arr(attrs[i].n1, s.n1); cast_arr(attrs[i].n2, s.n2);
+            cast_arr(attrs[i].uv0, s.uv0); cast_arr(attrs[i].uv1, s.uv1); cast_arr(attrs[i].uv2, s.uv2);
+            attrs[i].has_uv = s.has_uv;
+            attrs[i]._pad = 0;
+        }
+        std::vector<MaterialParams<R>> mparams(cs.material_params.size());
+        for (size_t i = 0; i < mparams.size(); i++) {
+            mparams[i].ior = R(cs.material_params[i].ior);
+            mparams[i].inv_ior = R(cs.material_params[i].inv_ior);
+        }
+        std::vector<TextureRec<R>> textures(cs.textures.size());
+        for (size_t i = 0; i < textures.size(); i++) {
+            const auto& s = cs.textures[i];
+            textures[i].type = s.type; textures[i].a = s.a; textures[i].b = s.b; textures[i].c = s.c;
+            cast_arr(textures[i].v, s.v);
+            textures[i].scale = R(s.scale);
+        }
+        int st;
+        if ((st = buf.upload(cs.ops, &view.ops)) != RT_OK) return st;
+        if ((st = buf.upload(bounds, &view.bounds)) != RT_OK) return st;
+        if ((st = buf.upload(cs.chain_offsets, &view.chain_offsets)) != RT_OK) return st;
+        if ((st = buf.upload(cs.chain_items, &view.chain_items)) != RT_OK) return st;
+        if ((st = buf.upload(xforms, &view.xforms)) != RT_OK) return st;
+        if ((st = buf.upload(spheres, &view.spheres)) != RT_OK) return st;
+        if ((st = buf.upload(planes, &view.planes)) != RT_OK) return st;
+        if ((st = buf.upload(suns, &view.suns)) != RT_OK) return st;
+        if ((st = buf.upload(cs.meshes, &view.meshes)) != RT_OK) return st;
+        if ((st = buf.upload(nodes, &view.nodes)) != RT_OK) return st;
+        if ((st = buf.upload(tris, &view.tris)) != RT_OK) return st;
+        if ((st = buf.upload(attrs, &view.attrs)) != RT_OK) return st;
+        if ((st = buf.upload(cs.materials, &view.materials)) != RT_OK) return st;
+        if ((st = buf.upload(mparams, &view.material_params)) != RT_OK) return st;
+        if ((st = buf.upload(textures, &view.textures)) != RT_OK) return st;
+        if ((st = buf.upload(cs.lights, &view.lights)) != RT_OK) return st;
+        view.n_lights = int32_t(cs.lights.size());
+        view.lights_is_list = cs.lights_is_list;
+        view.stack_entries = int32_t(cs.max_bvh_depth) + 2;
+        view.n_ops = int32_t(cs.ops.size());
+        return RT_OK;
+    }
+};
+
+}  // namespace rt
+
+struct RtScene {
+    int device = 0;
+    rt::CompiledScene compiled;
+    // Both precisions are materialised lazily on first use.
+    std::unique_ptr<rt::DeviceScene<double>> f64;
+    std::unique_ptr<rt::DeviceScene<float>> f32;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    rt::DeviceCounters* d_counters = nullptr;
+    RtRenderStats stats{};
+};
+
+namespace rt {
+
+template <typename R> CameraView<R> make_camera_view(const RtCameraDesc& c, const RtRenderParams& p) {
+    CameraView<R> v{};
+    for (int i = 0; i < 3; i++) {
+        v.position[i] = R(c.position[i]);
+        v.first_pixel[i] = R(c.first_pixel[i]);
+        v.pdu[i] = R(c.pixel_delta_u[i]);
+        v.pdv[i] = R(c.pixel_delta_v[i]);
+        v.basis_u[i] = R(c.basis_u[i]);
+        v.basis_v[i] = R(c.basis_v[i]);
+    }
+    v.aperture_radius = R(c.aperture_radius);
+    v.inv_sqrt_spt = R(1.0 / double(p.sqrt_spt));  // camera.rs:52
+    v.has_aperture = int32_t(c.has_aperture);
+    v.width = c.image_width;
+    v.height = c.image_height;
+    v.sqrt_spt = p.sqrt_spt;
+    v.thread_count = p.thread_count;
+    v.max_depth = p.max_depth;
+    return v;
+}
+
+template <typename R> ParamsView<R> make_params_view(const RtRenderParams& p, uint32_t owned) {
+    ParamsView<R> v{};
+    v.light_bias = R(p.light_bias);
+    for (int i = 0; i < 3; i++) v.background[i] = p.has_background ? R(p.background[i]) : R(0);
+    v.seed = p.seed;
+    v.band_rows = p.band_rows;
+    v.n_parts = p.n_parts;
+    v.part = p.part;
+    v.owned_rows = owned;
+    v.spp = double(p.sqrt_spt) * double(p.sqrt_spt) * double(p.thread_count);  // camera.rs:50-51
+    v.inv_spp = 1.0 / v.spp;
+    return v;
+}
+
+template <typename R>
+int render_typed(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, const RtRenderParams& p, uint32_t owned,
+                 double* d_out, hipStream_t stream) {
+    CameraView<R> cv = make_camera_view<R>(cam, p);
+    ParamsView<R> pv = make_params_view<R>(p, owned);
+    const uint32_t tiles_x = (cam.image_width + 15u) / 16u, tiles_y = (owned + 15u) / 16u;
+    const dim3 grid(tiles_x * tiles_y), block(256);
+    const size_t lds = size_t(ds.view.stack_entries) * 256 * sizeof(int);
+    if (lds > 160 * 1024) return set_err(RT_E_UNSUPPORTED, "mesh BVH too deep for the LDS traversal stack");
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), stream));
+    HIP_TRY(hipEventRecord(s->ev0, stream));
+    if (p.collect_stats)
+        hipLaunchKernelGGL((k_megakernel<R, true>), grid, block, lds, stream, ds.view, cv, pv, d_out, s->d_counters);
+    else
+        hipLaunchKernelGGL((k_megakernel<R, false>), grid, block, lds, stream, ds.view, cv, pv, d_out, s->d_counters);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev1, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    DeviceCounters hc{};
+    HIP_TRY(hipMemcpy(&hc, s->d_counters, sizeof hc, hipMemcpyDeviceToHost));
+    RtRenderStats& st = s->stats;
+    st = RtRenderStats{};
+    st.kernel_ms = ms;
+    st.traversal_kernel_ms = ms;
+    st.n_launches = 1;
+    st.pipeline_used = RT_PIPELINE_MEGAKERNEL;
+    st.samples = uint64_t(cam.image_width) * owned * uint64_t(pv.spp);
+    st.rays = hc.rays;
+    st.mesh_rays = hc.mesh_rays;
+    st.node_visits = hc.node_visits;
+    st.tri_tests = hc.tri_tests;
+    st.prim_tests = hc.prim_tests;
+    st.bytes_node = sizeof(BvhNode<R>);
+    st.bytes_tri = sizeof(TriRec<R>);
+    st.bytes_attr = sizeof(TriAttr<R>);
+    st.bytes_state = 0;
+    return RT_OK;
+}
+
+static uint32_t owned_rows(uint32_t h, const RtRenderParams* p) {
+    if (p->band_rows == 0 || p->n_parts <= 1) return h;
+    uint32_t n = 0;
+    for (uint32_t y = 0; y < h; y++)
+        if ((y / p->band_rows) % p->n_parts == p->part) n++;
+    return n;
+}
+
+}  // namespace rt
+
+extern "C" {
+
+const char* rt_last_error(void) { return rt::g_err.c_str(); }
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
+    using namespace rt;
+    if (!out) return set_err(RT_E_INVALID, "rt_scene_create: out is NULL");
+    *out = nullptr;
+    std::unique_ptr<RtScene> s(new (std::nothrow) RtScene);
+    if (!s) return set_err(RT_E_NOMEM, "out of memory");
+    std::string err;
+    int st = compile_scene(desc, &s->compiled, &err);
+    if (st != RT_OK) return set_err(st, err);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return set_err(RT_E_DEVICE, "no HIP device available");
+    if (device < 0 || device >= n) return set_err(RT_E_INVALID, "device index out of range");
+    s->device = device;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&s->ev0));
+    HIP_TRY(hipEventCreate(&s->ev1));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_counters), sizeof(DeviceCounters)));
+    *out = s.release();
+    return RT_OK;
+}
+
+void rt_scene_destroy(RtScene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    s->f64.reset();
+    s->f32.reset();
+    if (s->d_counters) (void)hipFree(s->d_counters);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+uint32_t rt_owned_rows(uint32_t image_height, const RtRenderParams* params) {
+    if (!params) return 0;
+    return rt::owned_rows(image_height, params);
+}
+
+int rt_render_device(const RtScene* scene, const RtCameraDesc* camera, const RtRenderParams* params,
+                     double* d_rgba_out, void* stream) {
+    using namespace rt;
+    if (!scene || !camera || !params || !d_rgba_out) return set_err(RT_E_INVALID, "rt_render_device: NULL argument");
+    if (params->sqrt_spt == 0 || params->thread_count == 0) return set_err(RT_E_INVALID, "sqrt_spt and thread_count must be positive");
+    if (params->n_parts > 1 && params->part >= params->n_parts) return set_err(RT_E_INVALID, "part >= n_parts");
+    if (camera->image_width == 0 || camera->image_height == 0) return set_err(RT_E_INVALID, "empty image");
+    if (uint64_t(params->sqrt_spt) * params->sqrt_spt * params->thread_count > 0xFFFFFFFFull)
+        return set_err(RT_E_UNSUPPORTED, "more than 2^32 samples per pixel");
+    RtScene* s = const_cast<RtScene*>(scene);  // stats + lazily built tables; the scene data itself is immutable
+    HIP_TRY(hipSetDevice(s->device));
+    uint32_t owned = owned_rows(camera->image_height, params);
+    if (owned == 0) return RT_OK;
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
+    if (params->pipeline == RT_PIPELINE_WAVEFRONT) return set_err(RT_E_UNSUPPORTED, "wavefront pipeline not built yet");
+    if (params->precision == RT_PRECISION_F32) {
+        if (!s->f32) {
+            auto ds = std::make_unique<DeviceScene<float>>();
+            int r = ds->build(s->compiled);
+            if (r != RT_OK) return r;
+            s->f32 = std::move(ds);
+        }
+        return render_typed<float>(s, *s->f32, *camera, *params, owned, d_rgba_out, st);
+    }
+    if (!s->f64) {
+        auto ds = std::make_unique<DeviceScene<double>>();
+        int r = ds->build(s->compiled);
+        if (r != RT_OK) return r;
+        s->f64 = std::move(ds);
+    }
+    return render_typed<double>(s, *s->f64, *camera, *params, owned, d_rgba_out, st);
+}
+
+int rt_render(const RtScene* scene, const RtCameraDesc* camera, const RtRenderParams* params, double* rgba_out) {
+    using namespace rt;
+    if (!scene || !camera || !params || !rgba_out) return set_err(RT_E_INVALID, "rt_render: NULL argument");
+    HIP_TRY(hipSetDevice(scene->device));
+    uint32_t owned = owned_rows(camera->image_height, params);
+    size_t bytes = size_t(owned) * camera->image_width * 4 * sizeof(double);
+    if (bytes == 0) return RT_OK;
+    double* d_out = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), bytes));
+    int st = rt_render_device(scene, camera, params, d_out, nullptr);
+    if (st == RT_OK) {
+        hipError_t e = hipMemcpy(rgba_out, d_out, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) st = set_err(RT_E_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(d_out);
+    return st;
+}
+
+// Diagnostic: traces ONE sample on the device and returns its radiance plus a per-bounce record
+// (8 doubles: t, pos xyz, material, op type, normal x, normal y).  Returns the bounce count.
+int rt_debug_trace_sample(const RtScene* scene, const RtCameraDesc* camera, const RtRenderParams* params,
+                          uint32_t tid, uint32_t x, uint32_t y, uint32_t sx, uint32_t sy,
+                          double* rgb_out, double* trace_out, uint32_t max_bounces) {
+    using namespace rt;
+    if (!scene || !camera || !params || !rgb_out || !trace_out) return set_err(RT_E_INVALID, "NULL argument");
+    RtScene* s = const_cast<RtScene*>(scene);
+    HIP_TRY(hipSetDevice(s->device));
+    double* d_buf = nullptr;
+    size_t n_d = 3 + size_t(max_bounces) * 8 + 1;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_buf), n_d * sizeof(double)));
+    HIP_TRY(hipMemset(d_buf, 0, n_d * sizeof(double)));
+    uint32_t* d_n = reinterpret_cast<uint32_t*>(d_buf + 3 + size_t(max_bounces) * 8);
+    if (params->precision == RT_PRECISION_F32) {
+        if (!s->f32) { auto ds = std::make_unique<DeviceScene<float>>(); int r = ds->build(s->compiled); if (r != RT_OK) return r; s->f32 = std::move(ds); }
+        size_t lds = size_t(s->f32->view.stack_entries) * 64 * sizeof(int);
+        hipLaunchKernelGGL((k_trace_sample<float>), dim3(1), dim3(64), lds, s->stream, s->f32->view, make_camera_view<float>(*camera, *params),
+                           make_params_view<float>(*params, camera->image_height), tid, x, y, sx, sy, d_buf, d_buf + 3, max_bounces, d_n);
+    } else {
+        if (!s->f64) { auto ds = std::make_unique<DeviceScene<double>>(); int r = ds->build(s->compiled); if (r != RT_OK) return r; s->f64 = std::move(ds); }
+        size_t lds = size_t(s->f64->view.stack_entries) * 64 * sizeof(int);
+        hipLaunchKernelGGL((k_trace_sample<double>), dim3(1), dim3(64), lds, s->stream, s->f64->view, make_camera_view<double>(*camera, *params),
+                           make_params_view<double>(*params, camera->image_height), tid, x, y, sx, sy, d_buf, d_buf + 3, max_bounces, d_n);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    std::vector<double> h(n_d);
+    HIP_TRY(hipMemcpy(h.data(), d_buf, n_d * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(d_buf);
+    std::memcpy(rgb_out, h.data(), 3 * sizeof(double));
+    std::memcpy(trace_out, h.data() + 3, size_t(max_bounces) * 8 * sizeof(double));
+    uint32_t n;
+    std::memcpy(&n, h.data() + 3 + size_t(max_bounces) * 8, sizeof n);
+    return int(n);
+}
+
+int rt_get_stats(const RtScene* scene, RtRenderStats* out) {
+    if (!scene || !out) return rt::set_err(RT_E_INVALID, "rt_get_stats: NULL argument");
+    *out = scene->stats;
+    return RT_OK;
+}
+
+}  // extern "C"

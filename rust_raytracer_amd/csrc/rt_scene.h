@@ -1,0 +1,181 @@
+// rt_scene.h — device-side scene layout (plain PODs, templated on the arithmetic type R).
+//
+// The reference keeps the scene as a graph of `Arc<dyn Hit>` trait objects that `test()`
+// walks recursively (src/object/*.rs).  On the GPU the same graph is flattened ONCE into
+//   * a linear "scene program" (Op[]) that reproduces the reference's depth-first visiting
+//     order, its bounds culling (skip pointers) and its closest-hit interval shrinking,
+//   * primitive tables (spheres, quads, sky/sun, mesh instances) in R,
+//   * one SAH BVH2 per triangle mesh with both child boxes stored in the parent node
+//     (replaces the reference's octree, src/object/mesh/octree.rs; same closest hit),
+//   * material / texture / light tables.
+#pragma once
+#include <cstdint>
+
+namespace rt {
+
+enum OpType : int32_t {
+    OP_END = 0,
+    OP_BOUNDS = 1,      // ObjectList / BVH node bounds test (list.rs:59, bvh.rs:85): arg = bounds idx, skip = pc when culled
+    OP_XFORM_PUSH = 2,  // Transform::test entry (transform.rs:124-127): arg = transform idx
+    OP_XFORM_POP = 3,   // leaving a Transform: ray goes back to the parent space (chain = parent chain)
+    OP_SPHERE = 4,      // arg = sphere idx
+    OP_PLANE = 5,       // arg = plane idx
+    OP_MESH = 6,        // arg = mesh instance idx
+    OP_SKY = 7,         // arg = material idx
+    OP_SUN = 8,         // arg = sun idx
+};
+
+struct Op {
+    int32_t type;
+    int32_t arg;
+    int32_t skip;   // OP_BOUNDS only
+    int32_t chain;  // index into chain_offsets: transforms enclosing this op, outermost first
+};
+
+template <typename R>
+struct Bounds {  // reference AxisAlignedBoundingBox, aabb.rs:7
+    R lo[3], hi[3];
+};
+
+template <typename R>
+struct Xform {  // Transform::transform / inv_transform (row-major, rows 0..2; row 3 is 0,0,0,1)
+    R m[12];
+    R inv[12];
+};
+
+template <typename R>
+struct SpherePrim {  // sphere.rs:18-24
+    R center[3];
+    R radius;
+    int32_t material;
+    int32_t _pad;
+};
+
+template <typename R>
+struct PlanePrim {  // plane.rs:14-27 (fields as computed by Plane::new, plane.rs:29-63)
+    R corner[3], normal[3], u[3], v[3], inv_u[3], inv_v[3];
+    R area;
+    int32_t material;
+    int32_t backface;
+};
+
+template <typename R>
+struct SunPrim {  // sun.rs:17-20
+    R direction[3];
+    int32_t material;
+    int32_t _pad;
+};
+
+struct MeshInst {
+    uint32_t node_base;  // first BVH node of this mesh in nodes[]
+    uint32_t tri_base;   // first triangle record in tris[] / attrs[]
+    int32_t material;
+    uint32_t flags;      // RT_MESH_* | MESH_HAS_UV
+    uint32_t n_tris;
+    uint32_t max_depth;
+};
+constexpr uint32_t MESH_HAS_UV = 0x100u;
+
+// BVH2 node: the two children's boxes live in the parent, so one fetch decides both.
+// child >= 0: inner node index (relative to node_base); child < 0: leaf,
+// ~child = (first_tri << 3) | (count - 1); kEmptyChild: no child.
+constexpr int32_t kEmptyChild = INT32_MIN;
+template <typename R>
+struct alignas(sizeof(R) == 8 ? 128 : 64) BvhNode {
+    R lo0[3], hi0[3], lo1[3], hi1[3];
+    int32_t c0, c1;
+};
+
+// Triangle record for the intersection test: v0 and the two edges (mesh.rs:69-70 computes the
+// edges per test; v1 - v0 done once on the host in the same arithmetic gives the same bits).
+template <typename R>
+struct alignas(16) TriRec {
+    R v0[3], e1[3], e2[3];
+    R _pad;
+};
+// Shading attributes, fetched only for the final closest hit.
+template <typename R>
+struct alignas(16) TriAttr {
+    R n0[3], n1[3], n2[3];  // vertex normals (mesh.rs:110-116)
+    R uv0[2], uv1[2], uv2[2];
+    int32_t has_uv;
+    int32_t _pad;
+};
+
+struct MaterialRec {  // material/*.rs
+    int32_t type;     // RtMaterialType
+    int32_t tex_a, tex_b, tex_c;
+    int32_t needs_uv; // any reachable texture reads (u, v)
+    int32_t _pad;
+};
+template <typename R>
+struct MaterialParams {
+    R ior;      // Dielectric::ior
+    R inv_ior;  // Glossy::inv_ior = 1 / ior (glossy.rs:30), computed in f64 then rounded
+};
+
+template <typename R>
+struct TextureRec {  // texture/*.rs
+    int32_t type;    // RtTextureType
+    int32_t a, b, c;
+    R v[3];
+    R scale;
+};
+
+enum LightKind : int32_t { LIGHT_OTHER = 0, LIGHT_PLANE = 1, LIGHT_SPHERE = 2, LIGHT_SKY = 3, LIGHT_SUN = 4 };
+struct LightRec {
+    int32_t kind;
+    int32_t index;  // into planes / spheres / suns
+};
+
+// Device pointers.  Passed to kernels by value.
+template <typename R>
+struct SceneView {
+    const Op* ops;
+    const Bounds<R>* bounds;
+    const int32_t* chain_offsets;  // chain c = chain_items[chain_offsets[c] .. chain_offsets[c+1])
+    const int32_t* chain_items;
+    const Xform<R>* xforms;
+    const SpherePrim<R>* spheres;
+    const PlanePrim<R>* planes;
+    const SunPrim<R>* suns;
+    const MeshInst* meshes;
+    const BvhNode<R>* nodes;
+    const TriRec<R>* tris;
+    const TriAttr<R>* attrs;
+    const MaterialRec* materials;
+    const MaterialParams<R>* material_params;
+    const TextureRec<R>* textures;
+    const LightRec* lights;
+    int32_t n_lights;
+    int32_t lights_is_list;  // lights root is an ObjectList (list.rs:80-100) vs a single object
+    int32_t stack_entries;   // per-lane LDS traversal stack size
+    int32_t n_ops;
+};
+
+template <typename R>
+struct CameraView {  // camera.rs:19-44
+    R position[3], first_pixel[3], pdu[3], pdv[3], basis_u[3], basis_v[3];
+    R aperture_radius;
+    R inv_sqrt_spt;
+    int32_t has_aperture;
+    uint32_t width, height;
+    uint32_t sqrt_spt, thread_count, max_depth;
+};
+
+template <typename R>
+struct ParamsView {
+    R light_bias;
+    R background[3];
+    uint64_t seed;
+    uint32_t band_rows, n_parts, part;  // row partition (see RtRenderParams)
+    uint32_t owned_rows;
+    double inv_spp;  // unused by the math (division is used), kept for diagnostics
+    double spp;
+};
+
+struct DeviceCounters {
+    unsigned long long rays, mesh_rays, node_visits, tri_tests, prim_tests;
+};
+
+}  // namespace rt

@@ -1,0 +1,45 @@
+"""Ad-hoc GPU vs oracle comparison (debug helper; the real checks live in tests/)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from rust_raytracer_amd import api
+from oracle import pyoracle
+
+def compare(args, label):
+    hs = api.HostScene(args)
+    t = time.time(); ref, ost = pyoracle.render(hs.desc, hs.camera, hs.params); to = time.time() - t
+    ds = api.DeviceScene(hs.desc, 0)
+    for prec, name in ((api.RT_PRECISION_F64, "f64"), (api.RT_PRECISION_F32, "f32")):
+        p = hs.params.copy(); p.precision = prec; p.collect_stats = 1
+        t = time.time(); img = ds.render(hs.camera, p); tg = time.time() - t
+        st = ds.stats()
+        a, b = img[..., :3], ref[..., :3]
+        both_nan = np.isnan(a) & np.isnan(b)
+        d = np.abs(a - b); d[both_nan] = 0
+        rel = d / np.maximum(np.abs(b), 1e-3)
+        if name == "f64":
+            bad = np.argwhere((rel > 1e-6).any(axis=2) | (np.isnan(a) != np.isnan(b)).any(axis=2))
+            np.set_printoptions(linewidth=220, precision=6, suppress=True)
+            for (yy, xx) in bad[:3]:
+                print("   mismatch px", (int(yy), int(xx)), "gpu", a[yy, xx], "ref", b[yy, xx])
+                S = hs.params.sqrt_spt
+                shown = 0
+                for sy in range(S):
+                    for sx in range(S):
+                        orgb, otr = pyoracle.trace_sample(hs.desc, hs.camera, hs.params, 0, int(xx), int(yy), sx, sy)
+                        grgb, gtr = ds.trace_sample(hs.camera, p, 0, int(xx), int(yy), sx, sy)
+                        if not np.allclose(orgb, grgb, rtol=1e-6, equal_nan=True) and shown < 2:
+                            shown += 1
+                            print("     sample", sx, sy, "oracle", orgb, "gpu", grgb)
+                            print("     oracle trace (t,pos,mat,kind,pdf,spdf)"); print(otr)
+                            print("     gpu trace (t,pos,mat,op,nx,ny)"); print(gtr)
+        print(f"[{label} {name}] {hs.width}x{hs.height}@{hs.spp} oracle {to:.2f}s gpu {tg:.3f}s kernel {st.kernel_ms:.2f}ms "
+              f"max_rel {np.nanmax(rel):.3e} frac(rel>1e-9) {np.mean(rel > 1e-9):.4f} frac(rel>1e-3) {np.mean(rel > 1e-3):.4f} "
+              f"mean gpu {a.mean():.6f} ref {b.mean():.6f} rays {st.rays} vs {ost.rays} prim {st.prim_tests} nodes {st.node_visits} tris {st.tri_tests}")
+    return hs
+
+if __name__ == "__main__":
+    print("devices", api.load_device_lib().rt_device_count())
+    for sc in sys.argv[1:] or ["sun_sky", "bvh_spheres", "hollow_glass", "nested_transform", "single_light", "sky_only"]:
+        compare(["tests/scenes/" + sc, "-s=16", "--seed=2"], sc)
+    compare(["-w=96", "-s=16", "--seed=7"], "default")
