@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the render hot path on N MI355X GPUs of one node.
+
+A "step" is ONE full pass of the hot path (`rt_render_device`, the drop-in for the
+reference's `Camera::render`, src/camera.rs:189) over the headline workload
+BASELINE.json names: scenes/cornell_dragon, 1200x1200, 1000 spp (10 replicas x 10x10
+strata), 870k-triangle mesh (deterministic stand-in, see tools/gen_dragon.cpp).  The scene
+(BVH, tables) is resident in HBM before the timed region; the frame stays in HBM.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME frame is row-tiled in
+interleaved 16-row bands across the ranks, each rank renders all samples of its rows, and
+one RCCL gather per step assembles the frame on rank 0 (inside the timed region).  Total
+work is fixed as N grows: "scaling": "strong".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
+`cpu_baseline` objects.  The CPU baseline runs the oracle (oracle/liboracle.so, a
+structure-faithful restatement of the reference's CPU path) on a bounded row subset.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+WORKLOADS = {
+    # name: (scene args, description)
+    "c4": (["scenes/cornell_dragon", "-w=1200", "-s=1000", "-t=10"],
+           "scenes/cornell_dragon 1200x1200 @1000spp (10 replicas x 10x10 strata), 871200-tri stand-in mesh"),
+    "c3": (["scenes/light_test", "-w=1200", "-s=1000", "-t=10"],
+           "scenes/light_test 1200x800 @1000spp, Suzanne 15.7k tri"),
+    "c2": (["scenes/cornell", "-w=800", "-s=256"], "scenes/cornell 800x800 @256spp, quads + glass sphere"),
+}
+
+
+def ensure_dragon():
+    path = os.path.join(REPO, "scenes", "resource", "dragon_high.obj")
+    if not os.path.exists(path):
+        tool = os.path.join(REPO, "tools", "gen_dragon")
+        if not os.path.exists(tool):
+            subprocess.run(["g++", "-std=c++17", "-O2", "-o", tool, tool + ".cpp"], check=True)
+        tmp = path + f".tmp{os.getpid()}"
+        subprocess.run([tool, tmp], check=True)
+        os.replace(tmp, path)
+
+
+def cpu_baseline(workload: str, seed: int):
+    """Times the CPU oracle on a bounded sample of the same workload (rank 0, N=1 only)."""
+    from rust_raytracer_amd import api
+    from oracle import pyoracle
+
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    args, _ = WORKLOADS[workload]
+    hs = api.HostScene(args + [f"--seed={seed}"])
+    p = hs.params.copy()
+    # Same per-sample work, bounded size: `cores` replicas of the workload's s x s strata, every
+    # `stride`-th row of the frame (an unbiased row subset, not a crop).  One OS thread per
+    # replica, exactly like the reference's -t flag.
+    p.thread_count = cores
+    target_samples = 1.2e6 * cores  # ~15-25 s at the oracle's speed on this class of host
+    per_row = hs.width * p.sqrt_spt * p.sqrt_spt * cores
+    n_rows = max(1, int(round(target_samples / per_row)))
+    stride = max(1, hs.height // n_rows)
+    p.band_rows, p.n_parts, p.part = 1, stride, stride // 2
+    t0 = time.time()
+    _, st = pyoracle.render(hs.desc, hs.camera, p)
+    wall = time.time() - t0
+    rows = len(api.owned_rows(hs.height, p))
+    return {
+        "value": st.samples / st.seconds / 1e6,
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{rows} rows (every {stride}th) x {hs.width} px x {cores} replicas x {p.sqrt_spt * p.sqrt_spt} strata "
+                  f"= {st.samples} samples in {st.seconds:.1f}s (octree build {wall - st.seconds:.1f}s excluded), "
+                  f"oracle/liboracle.so -O3 x86-64-v3, f64, recursive, reference octree",
+        "rays_per_sample": st.rays / max(st.samples, 1),
+        "node_tests_per_ray": st.node_tests / max(st.rays, 1),
+        "tri_tests_per_ray": st.tri_tests / max(st.rays, 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "mega", "wavefront"])
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--spp-divisor", type=int, default=1, help="debug: render spp/divisor (result is then labelled reduced)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--save-png", default="")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from rust_raytracer_amd import api
+    from rust_raytracer_amd import dist as rtdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP render path has no CPU fallback)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    if a.workload == "c4":
+        if rank == 0:
+            ensure_dragon()
+        if world > 1:
+            dist.barrier()
+    args, desc = WORKLOADS[a.workload]
+    args = list(args)
+    if a.spp_divisor > 1:
+        s = int([x for x in args if x.startswith("-s=")][0][3:]) // a.spp_divisor
+        args = [x for x in args if not x.startswith("-s=")] + [f"-s={s}"]
+    hs = api.HostScene(args + [f"--seed={a.seed}", f"--precision={a.precision}", f"--pipeline={a.pipeline}"])
+    scene = api.DeviceScene(hs.desc, local_rank)  # BVH build + upload: resident before timing
+    params = rtdist.partition_params(hs.params, world, rank)
+    rows = len(rtdist.rows_of_part(hs.height, world, rank))
+    out = torch.empty((rows, hs.width, 4), dtype=torch.float64, device=device)
+    stream = torch.cuda.current_stream(device)
+
+    frame_holder = {}
+
+    def step(collect_stats=False):
+        p = params.copy()
+        p.collect_stats = 1 if collect_stats else 0
+        scene.render_device(hs.camera, p, out.data_ptr(), stream.cuda_stream)
+        frame_holder["frame"] = rtdist.gather_frame(out, hs.height, hs.width)
+
+    # Warmup; the first warmup step also collects the traversal counters (deterministic for a
+    # given seed/config) that turn kernel time into algorithmic bytes.
+    counters = None
+    for i in range(a.warmup):
+        step(collect_stats=(i == 0))
+        if i == 0:
+            counters = scene.stats()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(a.steps):
+        step()
+        kernel_ms.append(scene.stats().traversal_kernel_ms)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_samples = hs.width * hs.height * hs.spp  # whole job, all ranks
+    value = total_samples * a.steps / elapsed / 1e6
+
+    roofline = None
+    if counters is not None and counters.rays > 0 and kernel_ms:
+        # Algorithmic bytes per launch of the dominant kernel (this rank's rows):
+        #   BVH nodes fetched x node size + triangle tests x triangle record size
+        #   + one attribute record per mesh closest hit (<= mesh_rays) + framebuffer write.
+        nbytes = (counters.node_visits * counters.bytes_node + counters.tri_tests * counters.bytes_tri +
+                  counters.mesh_rays * counters.bytes_attr + counters.rays * counters.bytes_state +
+                  rows * hs.width * 32)
+        avg_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = nbytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{a.workload}_{a.precision}")
+            except Exception:
+                traffic = None
+        roofline = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": "k_megakernel" if counters.pipeline_used == api.RT_PIPELINE_MEGAKERNEL else "k_wf_intersect",
+            "kernel_ms_avg": avg_ms, "algorithmic_bytes_per_launch": nbytes,
+            "rays_per_sample": counters.rays / max(counters.samples, 1),
+            "node_visits_per_ray": counters.node_visits / counters.rays,
+            "tri_tests_per_ray": counters.tri_tests / counters.rays,
+            "bytes_node": counters.bytes_node, "bytes_tri": counters.bytes_tri,
+        }
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.workload, a.seed)
+
+    if rank == 0:
+        if a.save_png and frame_holder.get("frame") is not None:
+            api.save_png(a.save_png, frame_holder["frame"].cpu().numpy())
+        line = {
+            "metric": "Msamples/sec (whole node), cornell_dragon 870k tri @1000spp" if a.workload == "c4"
+                      else f"Msamples/sec (whole node), {a.workload}",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": desc + (f" [DEBUG spp/{a.spp_divisor}]" if a.spp_divisor > 1 else ""),
+                       "image": [hs.width, hs.height], "spp": hs.spp, "seed": a.seed,
+                       "pipeline": a.pipeline, "partition": f"{rtdist.BAND_ROWS}-row bands round-robin over {world} GPU(s)"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if cpu:
+            line["speedup_vs_cpu_baseline"] = value / cpu["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1420,6 +1420,19 @@ int oracle_lights_pdf_value(const RtSceneDesc* scene, const double o[3], const d
     return RT_OK;
 }
 
+int oracle_lights_random(const RtSceneDesc* scene, const double o[3], uint64_t seed, uint32_t n, double* out3n) {
+    g_err.clear();
+    auto world = build_world(scene);
+    if (!world) return RT_E_INVALID;
+    Rng rng;
+    rng.key(seed, 0, 0, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        Vec4 d = world->lights->random(point(o[0], o[1], o[2]), rng);
+        out3n[3 * i] = d[0]; out3n[3 * i + 1] = d[1]; out3n[3 * i + 2] = d[2];
+    }
+    return RT_OK;
+}
+
 double oracle_reflectance(double cos_theta, double ior_ratio) { return reflectance(cos_theta, ior_ratio); }
 
 void oracle_onb_from_vec(const double w[3], double* out9) {

@@ -59,6 +59,9 @@ int oracle_world_hit(const RtSceneDesc* scene, const double origin[3], const dou
                      double t_min, double t_max, double* out11);
 /* lights.pdf_value(origin, dir) (list.rs:80-89, plane.rs:107-118, sphere.rs:106-121) */
 int oracle_lights_pdf_value(const RtSceneDesc* scene, const double origin[3], const double dir[3], double* out);
+/* n draws of lights.random(origin) (list.rs:91-100, plane.rs:120-126, sphere.rs:123-128) from one
+ * stream keyed by `seed`: out3n = n direction vectors */
+int oracle_lights_random(const RtSceneDesc* scene, const double origin[3], uint64_t seed, uint32_t n, double* out3n);
 /* utils.rs:31-36 */
 double oracle_reflectance(double cos_theta, double ior_ratio);
 /* utils.rs:17-28: out9 = columns u, v, w */

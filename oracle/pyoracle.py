@@ -50,6 +50,8 @@ def load() -> C.CDLL:
         lib.oracle_world_hit.restype = C.c_int
         lib.oracle_lights_pdf_value.argtypes = [C.POINTER(api.RtSceneDesc), dp, dp, dp]
         lib.oracle_lights_pdf_value.restype = C.c_int
+        lib.oracle_lights_random.argtypes = [C.POINTER(api.RtSceneDesc), dp, C.c_uint64, C.c_uint32, dp]
+        lib.oracle_lights_random.restype = C.c_int
         lib.oracle_reflectance.argtypes = [C.c_double, C.c_double]
         lib.oracle_reflectance.restype = C.c_double
         lib.oracle_onb_from_vec.argtypes = [dp, dp]
@@ -166,3 +168,28 @@ def trace_sample(desc, camera, params, tid, x, y, sx, sy, max_bounces=64):
     if n < 0:
         raise api.RtError(n, lib.oracle_last_error().decode())
     return np.array(list(rgb)), np.array(list(tr)).reshape(max_bounces, 8)[:min(n, max_bounces)]
+
+
+def lights_random(desc, origin, seed, n) -> np.ndarray:
+    lib = load()
+    out = (C.c_double * (3 * n))()
+    st = lib.oracle_lights_random(desc, _d3(origin), seed, n, out)
+    if st != 0:
+        raise api.RtError(st, lib.oracle_last_error().decode())
+    return np.array(list(out)).reshape(n, 3)
+
+
+def reflectance(cos_theta, ior_ratio) -> float:
+    return load().oracle_reflectance(cos_theta, ior_ratio)
+
+
+def onb_from_vec(w) -> np.ndarray:
+    out = (C.c_double * 9)()
+    load().oracle_onb_from_vec(_d3(w), out)
+    return np.array(list(out)).reshape(3, 3)  # rows = columns u, v, w
+
+
+def refract(v, n, ior_ratio) -> np.ndarray:
+    out = (C.c_double * 3)()
+    load().oracle_refract(_d3(v), _d3(n), ior_ratio, out)
+    return np.array(list(out))

@@ -1,0 +1,261 @@
+"""Parity of the HIP render path (through the C ABI, librt_mi355.so) with the CPU oracle.
+
+Tolerances (stated here, used below):
+  * f64 kernels vs oracle, same keyed RNG: the two differ only by FMA contraction, libm
+    (sin/cos/log/acos/atan2) ulps and the iterative-vs-recursive order of the radiance
+    products.  Bar: >= 99.8 % of channel values within 1e-9 relative (absolute floor 1e-12),
+    NaN pixels (reference 0/0 quirks) in exactly the same places, image mean within 1e-7.
+    Measured: max relative difference 1e-12 .. 2e-10, 0 values outside.
+  * f32 kernels vs oracle: individual paths may take different branches, so the bar is
+    statistical: image mean within 1 %, >= 95 % of values within max(5 % relative, 0.02).
+Everything here needs the GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from rust_raytracer_amd import api
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_frames.npz"))
+
+SCENES = {
+    "cornell": ["scenes/cornell", "-w=48", "-s=16", "--seed=1"],
+    "light_test": ["scenes/light_test", "-w=60", "-s=16", "--seed=2"],
+    "hollow_glass": ["tests/scenes/hollow_glass", "-w=48", "-s=16", "--seed=3"],
+    "nested_transform": ["tests/scenes/nested_transform", "-w=48", "-s=8", "-t=2", "--seed=4"],
+    "default": ["-w=60", "-s=16", "--seed=5"],
+    "sun_sky": ["tests/scenes/sun_sky", "-w=48", "-s=16", "--seed=6"],
+    "bvh_spheres": ["tests/scenes/bvh_spheres", "-w=48", "-s=16", "--seed=7"],
+    "single_light": ["tests/scenes/single_light", "-w=37", "-s=9", "--seed=8"],     # width not a tile multiple
+    "test": ["scenes/test", "-w=45", "-s=16", "--seed=9"],
+    "tonemap_test": ["scenes/tonemap_test", "-w=40", "-s=16", "--seed=10"],
+}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    lib = api.load_device_lib()
+    assert lib.rt_device_count() >= 1, "no HIP device: the GPU tests must run on the MI355X box"
+    return lib
+
+
+def assert_f64_parity(gpu, ref):
+    a, b = gpu[..., :3], ref[..., :3]
+    nan_a, nan_b = np.isnan(a), np.isnan(b)
+    np.testing.assert_array_equal(nan_a, nan_b)
+    fin = ~nan_b
+    rel = np.abs(a[fin] - b[fin]) / np.maximum(np.abs(b[fin]), 1e-3)
+    assert np.mean(rel > 1e-9) <= 0.002, f"{np.mean(rel > 1e-9):.4%} of values differ by more than 1e-9 (max {rel.max():.3e})"
+    assert abs(a[fin].mean() - b[fin].mean()) <= 1e-7 * max(abs(b[fin].mean()), 1.0)
+    assert np.all(gpu[..., 3] == 0.0)
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_f64_matches_oracle(dev, name):
+    hs = api.HostScene(SCENES[name])
+    ref, _ = pyoracle.render(hs.desc, hs.camera, hs.params)
+    scene = api.DeviceScene(hs.desc, 0)
+    gpu = scene.render(hs.camera, hs.params)
+    assert gpu.shape == ref.shape
+    assert_f64_parity(gpu, ref)
+
+
+@pytest.mark.parametrize("name", sorted(GOLD.files))
+def test_f64_matches_committed_golden_frames(dev, name):
+    hs = api.HostScene(SCENES[name])
+    gpu = api.DeviceScene(hs.desc, 0).render(hs.camera, hs.params)
+    assert_f64_parity(gpu, GOLD[name])
+
+
+@pytest.mark.parametrize("name", ["cornell", "light_test", "default", "nested_transform", "sun_sky"])
+def test_f32_is_statistically_equivalent(dev, name):
+    args = [a for a in SCENES[name] if not a.startswith("-s=")] + ["-s=64"]
+    hs = api.HostScene(args)
+    ref, _ = pyoracle.render(hs.desc, hs.camera, hs.params)
+    p = hs.params.copy()
+    p.precision = api.RT_PRECISION_F32
+    gpu = api.DeviceScene(hs.desc, 0).render(hs.camera, p)
+    a, b = gpu[..., :3], ref[..., :3]
+    assert not np.isnan(a).any()
+    assert abs(a.mean() - b.mean()) <= 0.01 * b.mean()
+    close = np.abs(a - b) <= np.maximum(0.05 * np.abs(b), 0.02)
+    assert close.mean() >= 0.95, f"only {close.mean():.3%} of f32 values are close to the f64 oracle"
+
+
+def test_stats_counters_and_collect_flag(dev):
+    hs = api.HostScene(SCENES["light_test"])
+    scene = api.DeviceScene(hs.desc, 0)
+    p = hs.params.copy()
+    p.collect_stats = 1
+    with_stats = scene.render(hs.camera, p)
+    st = scene.stats()
+    assert st.samples == hs.width * hs.height * hs.spp
+    assert st.rays >= st.samples and st.mesh_rays > 0 and st.node_visits > st.mesh_rays and st.tri_tests > 0
+    assert st.kernel_ms > 0 and st.bytes_node == 128 and st.bytes_tri == 80
+    p.collect_stats = 0
+    np.testing.assert_array_equal(scene.render(hs.camera, p), with_stats)   # counting never changes pixels
+    _, ost = pyoracle.render(hs.desc, hs.camera, hs.params)
+    # the GPU stops a path whose weight is exactly zero; the reference still traces it
+    assert st.rays <= ost.rays
+
+
+def test_single_sample_trace_matches_oracle(dev):
+    """Bounce by bounce: hit distance and position of individual paths."""
+    hs = api.HostScene(SCENES["default"])
+    scene = api.DeviceScene(hs.desc, 0)
+    for (x, y, sx, sy) in [(30, 20, 0, 0), (31, 14, 3, 2), (5, 35, 1, 1), (55, 3, 2, 3)]:
+        orgb, otr = pyoracle.trace_sample(hs.desc, hs.camera, hs.params, 0, x, y, sx, sy)
+        grgb, gtr = scene.trace_sample(hs.camera, hs.params, 0, x, y, sx, sy)
+        np.testing.assert_allclose(grgb, orgb, rtol=1e-9, atol=1e-12, equal_nan=True)
+        n = min(len(otr), len(gtr))          # the GPU may stop earlier on a zero weight
+        assert n >= 1
+        fin = np.isfinite(otr[:n, 0])
+        np.testing.assert_allclose(gtr[:n][fin][:, :4], otr[:n][fin][:, :4], rtol=1e-9, atol=1e-9)
+
+
+# ---------------------------------------------------------------- size-independent properties at full size
+def test_full_size_sky_only_is_exact(dev):
+    """1200x1200 @1000 spp (the headline sample count): every pixel is exactly L."""
+    hs = api.HostScene(["tests/scenes/sky_only", "-w=1200", "-s=1000", "-t=10"])
+    assert hs.spp == 1000
+    gpu = api.DeviceScene(hs.desc, 0).render(hs.camera, hs.params)
+    assert gpu.shape == (1200, 1200, 4)
+    assert np.all(gpu[..., 0] == 0.5) and np.all(gpu[..., 1] == 1.0) and np.all(gpu[..., 2] == 2.0)
+
+
+def ensure_dragon():
+    obj = os.path.join(api.REPO_DIR, "scenes", "resource", "dragon_high.obj")
+    if not os.path.exists(obj):
+        subprocess.run([os.path.join(api.REPO_DIR, "tools", "gen_dragon"), obj], check=True)
+
+
+def test_full_size_frame_row_partition_and_determinism(dev):
+    """Headline scene (871 200-triangle mesh) at 1200x1200, low spp: rendering the frame in
+    3 interleaved 16-row parts gives bit-identical pixels to the whole frame, and a second run
+    is bit-identical to the first (per-pixel accumulation order is fixed)."""
+    ensure_dragon()
+    hs = api.HostScene(["scenes/cornell_dragon", "-w=1200", "-s=4", "--seed=12"])
+    scene = api.DeviceScene(hs.desc, 0)
+    full = scene.render(hs.camera, hs.params)
+    again = scene.render(hs.camera, hs.params)
+    np.testing.assert_array_equal(full, again)
+    rebuilt = np.empty_like(full)
+    p = hs.params.copy()
+    p.band_rows, p.n_parts = 16, 3
+    for part in range(3):
+        p.part = part
+        rows = api.owned_rows(hs.height, p)
+        img = scene.render(hs.camera, p)
+        assert img.shape[0] == len(rows) == api.load_device_lib().rt_owned_rows(hs.height, C.byref(p))
+        rebuilt[rows] = img
+    np.testing.assert_array_equal(rebuilt, full)
+    # and a sparse sample of full-size pixels against the oracle (every 97th row)
+    q = hs.params.copy()
+    q.band_rows, q.n_parts, q.part = 1, 97, 5
+    ref, _ = pyoracle.render(hs.desc, hs.camera, q)
+    assert_f64_parity(full[api.owned_rows(hs.height, q)], ref)
+
+
+def test_emission_linearity_on_gpu(dev, tmp_path):
+    base = ("@config output_width = 64\n@config aspect_ratio = 1\n@config camera_pos = 0,1,5\n@config camera_target = 0,1,0\n"
+            "floor: plane 0,0,0 4,0,0 0,0,-4 (lambertian (constant 0.7,0.7,0.7))\n"
+            "ball: sphere 0,1,0 1 (glossy (constant 0.3,0.4,0.8) (constant 0.2))\n"
+            "lamp: sphere 2,3,2 0.5 (emissive (constant {e},{e},{e}))\nworld: list $floor $ball $lamp\nlights: list $lamp\n")
+    frames = []
+    for e in (8, 16):
+        f = tmp_path / f"s{e}"
+        f.write_text(base.format(e=e))
+        hs = api.HostScene([str(f), "-s=16", "--seed=9"])
+        frames.append(api.DeviceScene(hs.desc, 0).render(hs.camera, hs.params))
+    np.testing.assert_array_equal(frames[1], 2.0 * frames[0])
+
+
+# ---------------------------------------------------------------- edge cases and errors
+def test_empty_world_and_empty_lights(dev, tmp_path):
+    f = tmp_path / "empty"
+    f.write_text("@config output_width = 20\nworld: list\nlights: list\n")
+    hs = api.HostScene([str(f), "-s=4", "-b=0.25,0.5,1"])
+    ref, _ = pyoracle.render(hs.desc, hs.camera, hs.params)
+    gpu = api.DeviceScene(hs.desc, 0).render(hs.camera, hs.params)
+    assert np.all(gpu[..., :3] == np.array([0.25, 0.5, 1.0]))     # every ray misses: background (camera.rs:331)
+    np.testing.assert_array_equal(gpu, ref)
+
+
+def test_diffuse_with_empty_light_list(dev, tmp_path):
+    """ObjectList::random on an empty list returns (1,0,0) without a draw and pdf_value is 0
+    (list.rs:80-100): light-biased samples get weight 0 or NaN exactly like the reference."""
+    f = tmp_path / "nolights"
+    f.write_text("@config output_width = 24\n@config camera_pos = 0,1,4\n@config camera_target = 0,0.5,0\n"
+                 "floor: plane 0,0,0 4,0,0 0,0,-4 (lambertian (constant 0.7,0.7,0.7))\nsky: sky (constant 1,1,1)\n"
+                 "world: list $floor $sky\nlights: list\n")
+    hs = api.HostScene([str(f), "-s=16", "--seed=3"])
+    ref, _ = pyoracle.render(hs.desc, hs.camera, hs.params)
+    gpu = api.DeviceScene(hs.desc, 0).render(hs.camera, hs.params)
+    assert_f64_parity(gpu, ref)
+
+
+def test_tiny_and_ragged_images(dev):
+    for args in (["tests/scenes/single_light", "-w=1", "-s=4"], ["tests/scenes/single_light", "-w=17", "-r=0.37", "-s=4"],
+                 ["scenes/cornell", "-w=5", "-s=1"]):
+        hs = api.HostScene(args)
+        ref, _ = pyoracle.render(hs.desc, hs.camera, hs.params)
+        gpu = api.DeviceScene(hs.desc, 0).render(hs.camera, hs.params)
+        assert gpu.shape == (hs.height, hs.width, 4)
+        assert_f64_parity(gpu, ref)
+
+
+def test_max_depth_one_and_zero(dev):
+    for depth in (0, 1, 2):
+        hs = api.HostScene(["scenes/cornell", "-w=24", "-s=4", f"--max-depth={depth}"])
+        ref, _ = pyoracle.render(hs.desc, hs.camera, hs.params)
+        gpu = api.DeviceScene(hs.desc, 0).render(hs.camera, hs.params)
+        assert_f64_parity(gpu, ref)
+        if depth == 0:
+            assert np.all(gpu == 0.0)       # ray_color(depth = 0) = black (camera.rs:290)
+
+
+def test_error_codes(dev):
+    hs = api.HostScene(SCENES["cornell"])
+    scene = api.DeviceScene(hs.desc, 0)
+    p = hs.params.copy()
+    p.sqrt_spt = 0
+    with pytest.raises(api.RtError) as e:
+        scene.render(hs.camera, p)
+    assert e.value.status == api.RT_E_INVALID
+    p = hs.params.copy()
+    p.band_rows, p.n_parts, p.part = 16, 2, 2
+    with pytest.raises(api.RtError) as e:
+        scene.render(hs.camera, p)
+    assert e.value.status == api.RT_E_INVALID
+    with pytest.raises(api.RtError) as e:
+        api.DeviceScene(hs.desc, 99)
+    assert e.value.status == api.RT_E_INVALID
+    lib = api.load_device_lib()
+    assert lib.rt_render(None, None, None, None) == api.RT_E_INVALID
+    assert b"NULL" in lib.rt_last_error()
+    bad = api.RtSceneDesc()
+    C.memmove(C.byref(bad), hs.desc, C.sizeof(api.RtSceneDesc))
+    bad.world_root = 10 ** 6
+    h = C.c_void_p()
+    assert lib.rt_scene_create(C.byref(bad), 0, C.byref(h)) == api.RT_E_INVALID
+    bad.world_root = hs.desc.contents.world_root
+    bad.abi_version = 77
+    assert lib.rt_scene_create(C.byref(bad), 0, C.byref(h)) == api.RT_E_INVALID
+
+
+def test_render_device_keeps_frame_in_hbm(dev):
+    """rt_render_device writes into caller-owned device memory on the caller's stream."""
+    import torch
+    hs = api.HostScene(SCENES["cornell"])
+    scene = api.DeviceScene(hs.desc, 0)
+    out = torch.full((hs.height, hs.width, 4), -1.0, dtype=torch.float64, device="cuda:0")
+    stream = torch.cuda.Stream(device="cuda:0")
+    with torch.cuda.stream(stream):
+        scene.render_device(hs.camera, hs.params, out.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), scene.render(hs.camera, hs.params))

@@ -1,0 +1,241 @@
+"""Host-side logic (CPU only): CLI flags, scene DSL, OBJ loader, camera set-up, output stage,
+and that the C-ABI libraries export every symbol the headers declare.
+
+Known-answer values are hand-derived from the cited reference lines."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from rust_raytracer_amd import api
+
+
+def scene(*args):
+    return api.HostScene(list(args))
+
+
+# ---------------------------------------------------------------- config.rs:62-176
+def test_flag_defaults_match_reference():
+    hs = scene("scenes/cornell")
+    p = hs.params
+    assert (p.thread_count, p.max_depth, p.light_bias) == (1, 20, 0.25)      # config.rs:74-77
+    assert p.sqrt_spt == 15 and hs.spp == 225                                # floor(sqrt(250 / 1)) = 15
+    assert (hs.width, hs.height) == (600, 600)                               # scenes/cornell @config
+    assert p.has_background == 1 and list(p.background) == [0.0, 0.0, 0.0]   # config.rs:28
+
+
+def test_flag_forms_and_precedence():
+    # short and long forms, `--width=5` yields key `-width` (config.rs:63,85)
+    assert scene("scenes/cornell", "-w=128").width == 128
+    assert scene("scenes/cornell", "--width=64").width == 64
+    # CLI overrides the scene's @config (loaders/scene.rs:144)
+    hs = scene("scenes/light_test", "-w=300", "-r=2")
+    assert (hs.width, hs.height) == (300, 150)
+    # unknown keys and malformed args are ignored (config.rs:146)
+    assert scene("scenes/cornell", "--bogus=1", "-x", "-w=").width == 600
+    # actual spp = T * floor(sqrt(s / T))^2 (config.rs:154-155, README "samples" note)
+    hs = scene("scenes/cornell", "-s=1000", "-t=10")
+    assert (hs.params.sqrt_spt, hs.params.thread_count, hs.spp) == (10, 10, 1000)
+    hs = scene("scenes/cornell", "-s=1000", "-t=1")
+    assert (hs.params.sqrt_spt, hs.spp) == (31, 961)
+    hs = scene("scenes/cornell", "--max-depth=5", "--light-bias=0.5", "-b=0.1,0.2,0.3", "--seed=42")
+    assert hs.params.max_depth == 5 and hs.params.light_bias == 0.5 and hs.params.seed == 42
+    assert list(hs.params.background) == [0.1, 0.2, 0.3]
+
+
+def test_flag_errors_are_reported_not_aborted():
+    with pytest.raises(api.RtError):
+        scene("scenes/cornell", "-w=abc")          # reference: expect() panic
+    with pytest.raises(api.RtError):
+        scene("scenes/cornell", "--light-bias=2")  # reference: assert!
+    with pytest.raises(api.RtError):
+        scene("scenes/does_not_exist")
+    with pytest.raises(api.RtError):
+        scene("scenes/cornell", "-t=0")
+
+
+# ---------------------------------------------------------------- camera.rs:47-130
+def test_camera_known_answers_cornell_600():
+    hs = scene("scenes/cornell", "-w=600")
+    c = hs.camera
+    assert (c.image_width, c.image_height) == (600, 600)
+    np.testing.assert_allclose(list(c.basis_u), [-1, 0, 0], atol=1e-15)
+    np.testing.assert_allclose(list(c.basis_v), [0, 1, 0], atol=1e-15)
+    # h = 24/33, focus distance 800, viewport 581.8181..., pixel delta 0.969696...
+    np.testing.assert_allclose(list(c.pixel_delta_u), [-800 * 24 / 33 / 600, 0, 0], rtol=1e-14, atol=1e-15)
+    np.testing.assert_allclose(list(c.pixel_delta_v), [0, -800 * 24 / 33 / 600, 0], rtol=1e-14, atol=1e-15)
+    np.testing.assert_allclose(list(c.first_pixel), [567.9242424242424, 567.9242424242424, 0.0], rtol=1e-13, atol=1e-10)
+    assert c.has_aperture == 0
+
+
+def test_camera_height_truncates_and_aperture():
+    hs = scene("-w=400")                     # default scene: 400 / 1.5 = 266.67 -> 266 (camera.rs:87)
+    assert (hs.width, hs.height) == (400, 266)
+    assert hs.camera.has_aperture == 1
+    assert hs.camera.aperture_radius == pytest.approx((50.0 / 1000.0) / 2.8, rel=1e-15)  # camera.rs:125-129
+    cam = api.RtCameraDesc()
+    pos = (C.c_double * 3)(0, 0, 1)
+    tgt = (C.c_double * 3)(0, 0, 0)
+    api.load_host_lib().rth_make_camera(3, 1000.0, 50.0, -1.0, -1.0, pos, tgt, C.byref(cam))
+    assert cam.image_height == 1             # usize::max(1, ...)
+
+
+# ---------------------------------------------------------------- loaders/scene.rs
+def nodes_of(hs):
+    d = hs.desc.contents
+    return [d.nodes[i] for i in range(d.n_nodes)], d
+
+
+def test_dsl_cornell_structure():
+    hs = scene("scenes/cornell")
+    nodes, d = nodes_of(hs)
+    world = nodes[d.world_root]
+    kids = [d.child_indices[world.first_child + k] for k in range(world.n_children)]
+    types = [nodes[k].type for k in kids]
+    # floor ceiling back left right light box(transform) ball
+    assert types == [api.RT_NODE_PLANE] * 6 + [api.RT_NODE_TRANSFORM, api.RT_NODE_SPHERE]
+    light = nodes[kids[5]]
+    assert light.flags & 1                                   # `backface`
+    # `box` is re-declared referencing the old $box (later labels overwrite, scene.rs:108-125)
+    tr = nodes[kids[6]]
+    inner = nodes[d.child_indices[tr.first_child]]
+    assert inner.type == api.RT_NODE_LIST and inner.n_children == 6
+    lights = nodes[d.lights_root]
+    lk = [d.child_indices[lights.first_child + k] for k in range(lights.n_children)]
+    assert lk == [kids[5], kids[7]]                          # $light $ball: same shared nodes
+    # glass default ior 1.5 (scene.rs:616), glossy default ior 1.5 (scene.rs:625)
+    mats = [d.materials[i] for i in range(d.n_materials)]
+    assert any(m.type == api.RT_MAT_DIELECTRIC and m.ior == 1.5 for m in mats)
+    assert any(m.type == api.RT_MAT_GLOSSY and m.ior == 1.5 for m in mats)
+
+
+def test_dsl_transform_matrix_order():
+    """Each op left-multiplies M and right-multiplies M^-1 (transform.rs:49-96)."""
+    hs = scene("scenes/cornell")
+    nodes, d = nodes_of(hs)
+    t = [n for n in nodes if n.type == api.RT_NODE_TRANSFORM][0]
+    m = np.array(list(d.transforms[t.transform].m)).reshape(4, 4)
+    inv = np.array(list(d.transforms[t.transform].inv)).reshape(4, 4)
+    th = 18.0 / 180.0 * np.pi
+    ry = np.array([[np.cos(th), 0, np.sin(th), 0], [0, 1, 0, 0], [-np.sin(th), 0, np.cos(th), 0], [0, 0, 0, 1]])
+    T = lambda x, y, z: np.array([[1, 0, 0, x], [0, 1, 0, y], [0, 0, 1, z], [0, 0, 0, 1.0]])
+    expect = T(265, 0, 295) @ ry @ T(82.5, 165, 82.5)       # t=82.5,165,82.5 ry=18 t=265,0,295
+    np.testing.assert_allclose(m, expect, rtol=1e-14, atol=1e-12)
+    np.testing.assert_allclose(m @ inv, np.eye(4), atol=1e-12)
+
+
+def test_dsl_warnings_and_missing_world(tmp_path):
+    f = tmp_path / "bad"
+    f.write_text("mat: lambertian (constant 1,1,1)\nnot a declaration\nx: frobnicate 1 2\n"
+                 "s: sphere 0,0,0 1 $mat\nworld: list $s\nlights: list $s\n")
+    hs = scene(str(f))
+    assert "Warning: parse failed on line 1" in hs.log
+    assert "Warning: error on line 2" in hs.log and "Unknown object type" in hs.log
+    g = tmp_path / "noworld"
+    g.write_text("mat: lambertian (constant 1,1,1)\ns: sphere 0,0,0 1 $mat\nlights: list $s\n")
+    with pytest.raises(api.RtError, match="No world/lights object"):
+        scene(str(g))
+
+
+def test_dsl_aspect_ratio_division_and_inline():
+    hs = scene("scenes/light_test")
+    assert (hs.width, hs.height) == (600, 400)               # aspect_ratio = 3 / 2
+    hs = scene("scenes/test")                                # no @config at all: defaults (config.rs:20-29)
+    assert (hs.width, hs.height) == (600, 400)
+    nodes, d = nodes_of(hs)
+    assert sum(n.type == api.RT_NODE_SKY for n in nodes) == 1
+
+
+# ---------------------------------------------------------------- loaders/obj.rs
+def test_obj_loader_counts_and_normalisation():
+    hs = scene("scenes/light_test")
+    assert "Loaded 15744 tris" in hs.log                     # obj.rs:99
+    d = hs.desc.contents
+    m = d.meshes[0]
+    assert (m.n_triangles, m.n_positions, m.n_uvs, m.n_normals) == (15744, 7991, 10124, 7991)
+    nrm = np.ctypeslib.as_array(m.normals, shape=(m.n_normals, 3))
+    np.testing.assert_allclose(np.linalg.norm(nrm, axis=1), 1.0, rtol=1e-15, atol=1e-15)
+
+
+def test_obj_negative_indices_and_no_uv(tmp_path):
+    o = tmp_path / "t.obj"
+    o.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 2\nf -3//-1 -2//-1 -1//-1\n# c\ns off\n")
+    s = tmp_path / "s"
+    s.write_text(f"m: lambertian (constant 1,1,1)\nt: mesh t.obj $m\nworld: list $t\nlights: list $t\n")
+    hs = scene(str(s))
+    m = hs.desc.contents.meshes[0]
+    assert m.n_triangles == 1 and not m.tri_uv
+    assert [m.tri_pos[i] for i in range(3)] == [0, 1, 2]
+    assert [m.normals[i] for i in range(3)] == [0.0, 0.0, 1.0]   # normalised on load (obj.rs:48)
+
+
+# ---------------------------------------------------------------- output.rs + aces.rs
+@pytest.mark.parametrize("rgb,expect", [
+    ((0.18, 0.18, 0.18), (91, 91, 91)), ((1, 1, 1), (207, 207, 207)), ((2, 2, 2), (232, 232, 232)),
+    ((15, 15, 15), (254, 254, 254)), ((0.73, 0.73, 0.73), (190, 190, 190)),
+    ((0.65, 0.05, 0.05), (182, 29, 38)), ((0, 0, 0), (0, 0, 0)),
+])
+def test_output_stage_known_answers(rgb, expect):
+    px = np.array([[list(rgb) + [0.0]]], dtype=np.float64)
+    assert tuple(api.tonemap_rgb8(px)[0, 0]) == expect
+
+
+def test_output_stage_nan_and_png_roundtrip(tmp_path):
+    px = np.zeros((2, 3, 4))
+    px[0, 0, :3] = np.nan
+    px[1, 2, :3] = (1, 1, 1)
+    assert tuple(api.tonemap_rgb8(px)[0, 0]) == (0, 0, 0)    # NaN `as u8` = 0
+    path = str(tmp_path / "o.png")
+    api.save_png(path, px)
+    from PIL import Image
+    im = np.array(Image.open(path))
+    assert im.shape == (2, 3, 3) and im.dtype == np.uint8
+    np.testing.assert_array_equal(im, api.tonemap_rgb8(px))
+
+
+# ---------------------------------------------------------------- C ABI exports
+def declared_symbols(header):
+    text = open(header).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rth?_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_c_abi_exports_every_declared_symbol(repo_dir):
+    host = C.CDLL(os.path.join(repo_dir, "rust_raytracer_amd", "librt_host.so"))
+    for sym in declared_symbols(os.path.join(repo_dir, "include", "rt_host.h")):
+        assert hasattr(host, sym), sym
+    dev = api.load_device_lib()   # loads without a GPU; no compute call is made here
+    syms = declared_symbols(os.path.join(repo_dir, "include", "rt_mi355.h"))
+    assert "rt_render" in syms and "rt_scene_create" in syms
+    for sym in syms:
+        assert hasattr(dev, sym), sym
+    assert dev.rt_device_count() >= 0
+
+
+def test_struct_sizes_match_the_header(repo_dir, tmp_path):
+    """ctypes mirrors must have the C layout."""
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "rt_mi355.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(RtNode),sizeof(RtTransform),sizeof(RtMesh),sizeof(RtMaterial),sizeof(RtTexture),'
+                   'sizeof(RtSceneDesc),sizeof(RtCameraDesc),sizeof(RtRenderParams),sizeof(RtRenderStats));return 0;}\n')
+    exe = tmp_path / "sz"
+    import subprocess
+    subprocess.run(["gcc", "-I", os.path.join(repo_dir, "include"), "-o", str(exe), str(src)], check=True)
+    sizes = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    mirrors = [api.RtNode, api.RtTransform, api.RtMesh, api.RtMaterial, api.RtTexture, api.RtSceneDesc,
+               api.RtCameraDesc, api.RtRenderParams, api.RtRenderStats]
+    assert sizes == [C.sizeof(m) for m in mirrors]
+
+
+def test_scene_compiler_rejects_unsupported_without_gpu(tmp_path):
+    """rt_scene_create compiles the scene before touching the device, so feature errors are
+    reported on any machine: volumes are RT_E_UNSUPPORTED (-2), never silently dropped."""
+    s = tmp_path / "vol"
+    s.write_text("m: isotropic (constant 1,1,1)\nb: sphere 0,0,0 1 (glass)\nv: volume $b $m 0.5\n"
+                 "sky: sky (constant 1,1,1)\nworld: list $v $sky\nlights: list $sky\n")
+    hs = scene(str(s))
+    with pytest.raises(api.RtError) as e:
+        api.DeviceScene(hs.desc, 0)
+    assert e.value.status == api.RT_E_UNSUPPORTED
