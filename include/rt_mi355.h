@@ -240,8 +240,8 @@ int rt_render_device(const RtScene* scene, const RtCameraDesc* camera,
 int rt_get_stats(const RtScene* scene, RtRenderStats* out);
 
 /* Diagnostic probe (tests): traces ONE sample (replica tid, pixel x,y, stratum sx,sy) on the
- * device; rgb_out[3] = its radiance, trace_out[8*max_bounces] = per bounce: t, pos xyz,
- * material index, scene-program op type, normal x, normal y.  Returns the bounce count (>= 0)
+ * device; rgb_out[3] = its radiance, trace_out[17*max_bounces] = per bounce: t, pos xyz,
+ * material index, scene-program op type, triangle slot, 0, normal xyz, ray origin xyz, ray dir xyz.  Returns the bounce count (>= 0)
  * or a negative RtStatus. */
 int rt_debug_trace_sample(const RtScene* scene, const RtCameraDesc* camera, const RtRenderParams* params,
                           uint32_t tid, uint32_t x, uint32_t y, uint32_t sx, uint32_t sy,

@@ -9,9 +9,13 @@
 // "parity unpinned"): draws come from a keyed SplitMix64 stream re-keyed per sample
 // (seed, replica, pixel, stratum) instead of one sequential Pcg64Mcg per thread;
 // StandardNormal is Box-Muller on two uniforms instead of the ziggurat; U (`Standard`) and
-// R (`gen_range(0.0..1.0)`) are the same 53-bit uniform.  The ORDER and COUNT of draws per
+// R (`gen_range(0.0..1.0)`) are the same 53-bit uniform.  sin / cos / ln in the SAMPLING routines
+// come from include/rt_detmath.h (pure IEEE arithmetic, ~1 ulp) instead of the platform libm, so
+// that the GPU kernels can reproduce the oracle's paths bit for bit (Rust's own f64::sin is
+// platform-libm dependent too).  The ORDER and COUNT of draws per
 // sample follow the reference.
 #include "oracle.h"
+#include "../include/rt_detmath.h"
 
 #include <chrono>
 #include <cmath>
@@ -120,8 +124,8 @@ struct Rng {
     double normal() {                                                               // N
         double u1 = uniform();
         double u2 = uniform();
-        double r = std::sqrt(-2.0 * std::log(1.0 - u1));
-        return r * std::cos(2.0 * PI * u2);
+        double r = std::sqrt(-2.0 * det_log(1.0 - u1));
+        return r * det_cos(2.0 * PI * u2);
     }
     uint32_t below(uint32_t n) { return uint32_t(((next() >> 32) * uint64_t(n)) >> 32); }  // I(n)
 };
@@ -141,8 +145,8 @@ inline Vec4 random_cosine(Rng& rng) {  // vec4.rs:50-61
     double r2 = rng.uniform();
     double phi = r1 * 2.0 * PI;
     double sqrt_r2 = std::sqrt(r2);
-    double x = std::cos(phi) * sqrt_r2;
-    double y = std::sin(phi) * sqrt_r2;
+    double x = det_cos(phi) * sqrt_r2;
+    double y = det_sin(phi) * sqrt_r2;
     double z = std::sqrt(1.0 - r2);
     return vec(x, y, z);
 }
@@ -469,8 +473,8 @@ Vec4 random_to_sphere(double radius, double distance_squared, Rng& rng) {  // sp
     double r2 = rng.uniform();
     double phi = r1 * 2.0 * PI;
     double z = 1.0 + r2 * (cos_theta_max - 1.0);
-    double x = std::cos(phi) * std::sqrt(1.0 - z * z);
-    double y = std::sin(phi) * std::sqrt(1.0 - z * z);
+    double x = det_cos(phi) * std::sqrt(1.0 - z * z);
+    double y = det_sin(phi) * std::sqrt(1.0 - z * z);
     return vec(x, y, z);
 }
 struct Sphere : Hit {
@@ -925,7 +929,7 @@ struct Volume : Hit {
                 t_min = std::fmax(t_min, 0.0);
                 double ray_len = length(ray.dir);
                 double dist_inside_boundary = (t_max - t_min) * ray_len;
-                double hit_dist = neg_inv_density * std::log(rng.uniform());
+                double hit_dist = neg_inv_density * det_log(rng.uniform());
                 if (hit_dist > dist_inside_boundary) return false;
                 double tt = t_min + hit_dist / ray_len;
                 Vec4 hit_pos = ray.at(tt);
@@ -1182,8 +1186,9 @@ std::unique_ptr<World> build_world(const RtSceneDesc* d) {
     return w;
 }
 
-// Optional per-bounce trace (debugging / tests): 8 doubles per bounce:
-// t, pos.xyz, material index, scatter kind (0 pdf, 1 ray, 2 absorbed, 3 emissive, -1 miss), pdf, scattering_pdf
+// Optional per-bounce trace (debugging / tests): 16 doubles per bounce:
+// t, pos.xyz, material index, scatter kind (0 pdf, 1 ray, 2 absorbed, 3 emissive, -1 miss), pdf, scattering_pdf,
+// normal.xyz, ray origin.xyz, ray dir.xy (dir.z in slot 15)
 thread_local std::vector<double>* g_trace = nullptr;
 
 // ------------------------------------------------------------------ camera.rs
@@ -1234,7 +1239,10 @@ struct Camera {
             if (g_trace) {
                 trace_at = g_trace->size();
                 g_trace->insert(g_trace->end(), {hit.t, hit.hit_pos[0], hit.hit_pos[1], hit.hit_pos[2],
-                                                 double(hit.material_index), double(int(sr.kind)), 0.0, 0.0});
+                                                 double(hit.material_index), double(int(sr.kind)), 0.0, 0.0,
+                                                 hit.normal[0], hit.normal[1], hit.normal[2],
+                                                 ray.origin[0], ray.origin[1], ray.origin[2], ray.dir[0], ray.dir[1]});
+                g_trace->push_back(ray.dir[2]);
             }
             switch (sr.kind) {
                 case ScatterKind::WithPDF: {
@@ -1262,7 +1270,8 @@ struct Camera {
                     return from_emission;
             }
         }
-        if (g_trace) g_trace->insert(g_trace->end(), {INF, 0, 0, 0, -1, -1, 0, 0});
+        if (g_trace) g_trace->insert(g_trace->end(), {INF, 0, 0, 0, -1, -1, 0, 0, 0, 0, 0,
+                                                      ray.origin[0], ray.origin[1], ray.origin[2], ray.dir[0], ray.dir[1], ray.dir[2]});
         return background;
     }
 };
@@ -1433,6 +1442,11 @@ int oracle_lights_random(const RtSceneDesc* scene, const double o[3], uint64_t s
     return RT_OK;
 }
 
+void oracle_detmath(double x, double* out3) {
+    det_sincos(x, &out3[0], &out3[1]);
+    out3[2] = x > 0 ? det_log(x) : 0.0;
+}
+
 double oracle_reflectance(double cos_theta, double ior_ratio) { return reflectance(cos_theta, ior_ratio); }
 
 void oracle_onb_from_vec(const double w[3], double* out9) {
@@ -1476,9 +1490,9 @@ int oracle_trace_sample(const RtSceneDesc* scene, const RtCameraDesc* camera, co
     Vec4 c = cam.ray_color(ray, world->world, lights_pdf, params->max_depth, rng);
     g_trace = nullptr;
     rgb_out[0] = c[0]; rgb_out[1] = c[1]; rgb_out[2] = c[2];
-    uint32_t n = uint32_t(trace.size() / 8);
+    uint32_t n = uint32_t(trace.size() / 17);
     for (uint32_t i = 0; i < n && i < max_bounces; i++)
-        for (int k = 0; k < 8; k++) trace_out[8 * i + k] = trace[8 * i + k];
+        for (int k = 0; k < 17; k++) trace_out[17 * i + k] = trace[17 * i + k];
     return int(n);
 }
 

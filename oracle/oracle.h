@@ -62,6 +62,8 @@ int oracle_lights_pdf_value(const RtSceneDesc* scene, const double origin[3], co
 /* n draws of lights.random(origin) (list.rs:91-100, plane.rs:120-126, sphere.rs:123-128) from one
  * stream keyed by `seed`: out3n = n direction vectors */
 int oracle_lights_random(const RtSceneDesc* scene, const double origin[3], uint64_t seed, uint32_t n, double* out3n);
+/* include/rt_detmath.h: out3 = det_sin(x), det_cos(x), det_log(x) */
+void oracle_detmath(double x, double* out3);
 /* utils.rs:31-36 */
 double oracle_reflectance(double cos_theta, double ior_ratio);
 /* utils.rs:17-28: out9 = columns u, v, w */
@@ -75,8 +77,9 @@ void oracle_rng_raw(uint64_t seed, uint32_t tid, uint64_t pixel, uint32_t stratu
 void oracle_get_ray(const RtCameraDesc* camera, const RtRenderParams* params, uint32_t tid,
                     uint32_t x, uint32_t y, uint32_t sx, uint32_t sy, double* out6);
 
-/* ray_color for ONE sample with a per-bounce trace (8 doubles per bounce: t, pos xyz, material,
- * scatter kind 0 pdf / 1 ray / 2 absorbed / 3 emissive / -1 miss, mix pdf, scattering pdf).
+/* ray_color for ONE sample with a per-bounce trace (17 doubles per bounce: t, pos xyz, material,
+ * scatter kind 0 pdf / 1 ray / 2 absorbed / 3 emissive / -1 miss, mix pdf, scattering pdf,
+ * normal xyz, ray origin xyz, ray dir xyz).
  * Returns the number of bounces recorded. */
 int oracle_trace_sample(const RtSceneDesc* scene, const RtCameraDesc* camera, const RtRenderParams* params,
                         uint32_t tid, uint32_t x, uint32_t y, uint32_t sx, uint32_t sy, double* rgb_out,

@@ -52,6 +52,8 @@ def load() -> C.CDLL:
         lib.oracle_lights_pdf_value.restype = C.c_int
         lib.oracle_lights_random.argtypes = [C.POINTER(api.RtSceneDesc), dp, C.c_uint64, C.c_uint32, dp]
         lib.oracle_lights_random.restype = C.c_int
+        lib.oracle_detmath.argtypes = [C.c_double, dp]
+        lib.oracle_detmath.restype = None
         lib.oracle_reflectance.argtypes = [C.c_double, C.c_double]
         lib.oracle_reflectance.restype = C.c_double
         lib.oracle_onb_from_vec.argtypes = [dp, dp]
@@ -160,14 +162,14 @@ def get_ray(camera, params, tid, x, y, sx, sy) -> np.ndarray:
 
 
 def trace_sample(desc, camera, params, tid, x, y, sx, sy, max_bounces=64):
-    """(rgb, trace[n, 8]) of one sample; see oracle.h oracle_trace_sample."""
+    """(rgb, trace[n, 17]) of one sample; see oracle.h oracle_trace_sample."""
     lib = load()
     rgb = (C.c_double * 3)()
-    tr = (C.c_double * (8 * max_bounces))()
+    tr = (C.c_double * (17 * max_bounces))()
     n = lib.oracle_trace_sample(desc, C.byref(camera), C.byref(params), tid, x, y, sx, sy, rgb, tr, max_bounces)
     if n < 0:
         raise api.RtError(n, lib.oracle_last_error().decode())
-    return np.array(list(rgb)), np.array(list(tr)).reshape(max_bounces, 8)[:min(n, max_bounces)]
+    return np.array(list(rgb)), np.array(list(tr)).reshape(max_bounces, 17)[:min(n, max_bounces)]
 
 
 def lights_random(desc, origin, seed, n) -> np.ndarray:
@@ -192,4 +194,11 @@ def onb_from_vec(w) -> np.ndarray:
 def refract(v, n, ior_ratio) -> np.ndarray:
     out = (C.c_double * 3)()
     load().oracle_refract(_d3(v), _d3(n), ior_ratio, out)
+    return np.array(list(out))
+
+
+def detmath(x) -> np.ndarray:
+    """(det_sin(x), det_cos(x), det_log(x)) of include/rt_detmath.h."""
+    out = (C.c_double * 3)()
+    load().oracle_detmath(float(x), out)
     return np.array(list(out))

@@ -120,7 +120,7 @@ class RtError(RuntimeError):
 
 
 HOST_LIB_PATH = os.path.join(PKG_DIR, "librt_host.so")
-DEVICE_LIB_PATH = os.path.join(PKG_DIR, "librt_mi355.so")
+DEVICE_LIB_PATH = os.environ.get("RT_DEVICE_LIB") or os.path.join(PKG_DIR, "librt_mi355.so")  # env override: A/B builds
 
 _host_lib = None
 _device_lib = None
@@ -298,14 +298,14 @@ class DeviceScene:
             raise RtError(st, self._lib.rt_last_error().decode())
 
     def trace_sample(self, camera, params, tid, x, y, sx, sy, max_bounces=64):
-        """Diagnostic: (rgb[3], trace[n, 8]) of one sample traced on the device."""
+        """Diagnostic: (rgb[3], trace[n, 17]) of one sample traced on the device."""
         rgb = (C.c_double * 3)()
-        tr = (C.c_double * (8 * max_bounces))()
+        tr = (C.c_double * (17 * max_bounces))()
         n = self._lib.rt_debug_trace_sample(self._h, C.byref(camera), C.byref(params), tid, x, y, sx, sy,
                                             rgb, tr, max_bounces)
         if n < 0:
             raise RtError(n, self._lib.rt_last_error().decode())
-        return np.array(list(rgb)), np.array(list(tr)).reshape(max_bounces, 8)[:min(n, max_bounces)]
+        return np.array(list(rgb)), np.array(list(tr)).reshape(max_bounces, 17)[:min(n, max_bounces)]
 
     def stats(self) -> RtRenderStats:
         s = RtRenderStats()

@@ -10,6 +10,7 @@
 
 #include <cfloat>
 
+#include "../../include/rt_detmath.h"
 #include "../../include/rt_mi355.h"
 #include "rt_scene.h"
 
@@ -115,11 +116,19 @@ struct Rng {
 template <typename R> RT_DEV R rng_uniform(Rng& g);
 template <> RT_DEV double rng_uniform<double>(Rng& g) { return double(g.next() >> 11) * (1.0 / 9007199254740992.0); }
 template <> RT_DEV float rng_uniform<float>(Rng& g) { return float(g.next() >> 40) * (1.0f / 16777216.0f); }
+// sin / cos / ln of the sampling routines: f64 uses the deterministic functions shared with the
+// oracle (include/rt_detmath.h), f32 the device libm.
+RT_DEV void sincos_r(double x, double& s, double& c) { det_sincos(x, &s, &c); }
+RT_DEV void sincos_r(float x, float& s, float& c) { s = sinf(x); c = cosf(x); }
+RT_DEV double log_r(double x) { return det_log(x); }
+RT_DEV float log_r(float x) { return logf(x); }
 template <typename R> RT_DEV R rng_normal(Rng& g) {  // Box-Muller, cosine branch
     R u1 = rng_uniform<R>(g);
     R u2 = rng_uniform<R>(g);
-    R r = sqrt(R(-2) * log(R(1) - u1));
-    return r * cos(R(2) * pi<R>() * u2);
+    R r = sqrt(R(-2) * log_r(R(1) - u1));
+    R s, c;
+    sincos_r(R(2) * pi<R>() * u2, s, c);
+    return r * c;
 }
 template <typename R> RT_DEV V3<R> random_unit(Rng& g) {  // vec4.rs:42-48
     R x = rng_normal<R>(g);
@@ -132,8 +141,10 @@ template <typename R> RT_DEV V3<R> random_cosine(Rng& g) {  // vec4.rs:50-61
     R r2 = rng_uniform<R>(g);
     R phi = r1 * R(2) * pi<R>();
     R sqrt_r2 = sqrt(r2);
-    R x = cos(phi) * sqrt_r2;
-    R y = sin(phi) * sqrt_r2;
+    R sn, cs;
+    sincos_r(phi, sn, cs);
+    R x = cs * sqrt_r2;
+    R y = sn * sqrt_r2;
     R z = sqrt(R(1) - r2);
     return mk<R>(x, y, z);
 }
@@ -583,8 +594,10 @@ template <typename R> RT_DEV V3<R> light_random(const SceneView<R>& sc, const Li
             R r2 = rng_uniform<R>(rng);
             R phi = r1 * R(2) * pi<R>();
             R z = R(1) + r2 * (cos_theta_max - R(1));
-            R x = cos(phi) * sqrt(R(1) - z * z);
-            R y = sin(phi) * sqrt(R(1) - z * z);
+            R sn, cs;
+            sincos_r(phi, sn, cs);
+            R x = cs * sqrt(R(1) - z * z);
+            R y = sn * sqrt(R(1) - z * z);
             return basis_apply(bu, bv, dir, mk<R>(x, y, z));
         }
         case LIGHT_SKY: return random_unit<R>(rng);           // sky.rs:65-67

@@ -108,7 +108,8 @@ __global__ void __launch_bounds__(256) k_megakernel(SceneView<R> sc, CameraView<
 }
 
 // Diagnostic probe: one sample traced by one lane, with a per-bounce record
-// (t, pos xyz, material, op type, 0, 0).  Used by the parity tests to localise differences.
+// (17 doubles: t, pos xyz, material, op type, triangle slot, 0, normal xyz, ray origin xyz, ray dir xyz).
+// Used by the parity tests to localise differences.
 template <typename R>
 __global__ void k_trace_sample(SceneView<R> sc, CameraView<R> cam, ParamsView<R> prm, uint32_t tid, uint32_t px, uint32_t py,
                                uint32_t sx, uint32_t sy, double* rgb, double* trace, uint32_t max_bounces, uint32_t* n_out) {
@@ -127,17 +128,19 @@ __global__ void k_trace_sample(SceneView<R> sc, CameraView<R> cam, ParamsView<R>
         Best<R> best;
         world_test<R, false>(sc, ps.ray, R(0.001), best, lds_stack, int(blockDim.x), cnt);
         if (n < max_bounces) {
-            double* t = trace + 8 * n;
+            double* t = trace + 17 * n;
+            for (int k = 0; k < 17; k++) t[k] = 0;
             t[0] = double(best.t);
+            t[4] = -1; t[5] = -1; t[6] = double(best.tri);
             if (best.pc >= 0) {
                 HitInfo<R> h = resolve_hit(sc, ps.ray, best);
                 t[1] = double(h.pos.x); t[2] = double(h.pos.y); t[3] = double(h.pos.z);
                 t[4] = double(h.material);
                 t[5] = double(sc.ops[best.pc].type);
-                t[6] = double(h.normal.x); t[7] = double(h.normal.y);
-            } else {
-                t[1] = t[2] = t[3] = 0; t[4] = -1; t[5] = -1; t[6] = t[7] = 0;
+                t[8] = double(h.normal.x); t[9] = double(h.normal.y); t[10] = double(h.normal.z);
             }
+            t[11] = double(ps.ray.o.x); t[12] = double(ps.ray.o.y); t[13] = double(ps.ray.o.z);
+            t[14] = double(ps.ray.d.x); t[15] = double(ps.ray.d.y); t[16] = double(ps.ray.d.z);
         }
         n++;
         bool cont = shade<R, false>(sc, prm, ps, best, rng, cnt);
@@ -402,6 +405,16 @@ int render_typed(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, const 
     return RT_OK;
 }
 
+static int validate_render_args(const RtCameraDesc* camera, const RtRenderParams* params) {
+    if (params->sqrt_spt == 0 || params->thread_count == 0) return set_err(RT_E_INVALID, "sqrt_spt and thread_count must be positive");
+    if (params->band_rows != 0 && params->n_parts > 1 && params->part >= params->n_parts) return set_err(RT_E_INVALID, "part >= n_parts");
+    if (camera->image_width == 0 || camera->image_height == 0) return set_err(RT_E_INVALID, "empty image");
+    if (uint64_t(params->sqrt_spt) * params->sqrt_spt * params->thread_count > 0xFFFFFFFFull)
+        return set_err(RT_E_UNSUPPORTED, "more than 2^32 samples per pixel");
+    if (params->precision != RT_PRECISION_F64 && params->precision != RT_PRECISION_F32) return set_err(RT_E_INVALID, "unknown precision");
+    return RT_OK;
+}
+
 static uint32_t owned_rows(uint32_t h, const RtRenderParams* p) {
     if (p->band_rows == 0 || p->n_parts <= 1) return h;
     uint32_t n = 0;
@@ -465,11 +478,7 @@ int rt_render_device(const RtScene* scene, const RtCameraDesc* camera, const RtR
                      double* d_rgba_out, void* stream) {
     using namespace rt;
     if (!scene || !camera || !params || !d_rgba_out) return set_err(RT_E_INVALID, "rt_render_device: NULL argument");
-    if (params->sqrt_spt == 0 || params->thread_count == 0) return set_err(RT_E_INVALID, "sqrt_spt and thread_count must be positive");
-    if (params->n_parts > 1 && params->part >= params->n_parts) return set_err(RT_E_INVALID, "part >= n_parts");
-    if (camera->image_width == 0 || camera->image_height == 0) return set_err(RT_E_INVALID, "empty image");
-    if (uint64_t(params->sqrt_spt) * params->sqrt_spt * params->thread_count > 0xFFFFFFFFull)
-        return set_err(RT_E_UNSUPPORTED, "more than 2^32 samples per pixel");
+    if (int v = validate_render_args(camera, params)) return v;
     RtScene* s = const_cast<RtScene*>(scene);  // stats + lazily built tables; the scene data itself is immutable
     HIP_TRY(hipSetDevice(s->device));
     uint32_t owned = owned_rows(camera->image_height, params);
@@ -497,6 +506,7 @@ int rt_render_device(const RtScene* scene, const RtCameraDesc* camera, const RtR
 int rt_render(const RtScene* scene, const RtCameraDesc* camera, const RtRenderParams* params, double* rgba_out) {
     using namespace rt;
     if (!scene || !camera || !params || !rgba_out) return set_err(RT_E_INVALID, "rt_render: NULL argument");
+    if (int v = validate_render_args(camera, params)) return v;
     HIP_TRY(hipSetDevice(scene->device));
     uint32_t owned = owned_rows(camera->image_height, params);
     size_t bytes = size_t(owned) * camera->image_width * 4 * sizeof(double);
@@ -513,7 +523,7 @@ int rt_render(const RtScene* scene, const RtCameraDesc* camera, const RtRenderPa
 }
 
 // Diagnostic: traces ONE sample on the device and returns its radiance plus a per-bounce record
-// (8 doubles: t, pos xyz, material, op type, normal x, normal y).  Returns the bounce count.
+// (17 doubles, see k_trace_sample).  Returns the bounce count.
 int rt_debug_trace_sample(const RtScene* scene, const RtCameraDesc* camera, const RtRenderParams* params,
                           uint32_t tid, uint32_t x, uint32_t y, uint32_t sx, uint32_t sy,
                           double* rgb_out, double* trace_out, uint32_t max_bounces) {
@@ -522,10 +532,10 @@ int rt_debug_trace_sample(const RtScene* scene, const RtCameraDesc* camera, cons
     RtScene* s = const_cast<RtScene*>(scene);
     HIP_TRY(hipSetDevice(s->device));
     double* d_buf = nullptr;
-    size_t n_d = 3 + size_t(max_bounces) * 8 + 1;
+    size_t n_d = 3 + size_t(max_bounces) * 17 + 1;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_buf), n_d * sizeof(double)));
     HIP_TRY(hipMemset(d_buf, 0, n_d * sizeof(double)));
-    uint32_t* d_n = reinterpret_cast<uint32_t*>(d_buf + 3 + size_t(max_bounces) * 8);
+    uint32_t* d_n = reinterpret_cast<uint32_t*>(d_buf + 3 + size_t(max_bounces) * 17);
     if (params->precision == RT_PRECISION_F32) {
         if (!s->f32) { auto ds = std::make_unique<DeviceScene<float>>(); int r = ds->build(s->compiled); if (r != RT_OK) return r; s->f32 = std::move(ds); }
         size_t lds = size_t(s->f32->view.stack_entries) * 64 * sizeof(int);
@@ -543,9 +553,9 @@ int rt_debug_trace_sample(const RtScene* scene, const RtCameraDesc* camera, cons
     HIP_TRY(hipMemcpy(h.data(), d_buf, n_d * sizeof(double), hipMemcpyDeviceToHost));
     (void)hipFree(d_buf);
     std::memcpy(rgb_out, h.data(), 3 * sizeof(double));
-    std::memcpy(trace_out, h.data() + 3, size_t(max_bounces) * 8 * sizeof(double));
+    std::memcpy(trace_out, h.data() + 3, size_t(max_bounces) * 17 * sizeof(double));
     uint32_t n;
-    std::memcpy(&n, h.data() + 3 + size_t(max_bounces) * 8, sizeof n);
+    std::memcpy(&n, h.data() + 3 + size_t(max_bounces) * 17, sizeof n);
     return int(n);
 }
 
