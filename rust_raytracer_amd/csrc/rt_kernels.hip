@@ -2,7 +2,9 @@
 // gfx950 only: 64-lane waves, per-lane traversal stack in LDS, HIP events on the launch stream.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -12,6 +14,7 @@
 
 #include "rt_compile.h"
 #include "rt_device.h"
+#include "rt_wavefront.h"
 
 namespace rt {
 
@@ -325,6 +328,21 @@ struct RtScene {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     rt::DeviceCounters* d_counters = nullptr;
     RtRenderStats stats{};
+    // wavefront pipeline resources (allocated on first use, reused between renders)
+    struct Wavefront {
+        uint32_t capacity = 0;
+        size_t real_size = 0;          // sizeof(R) the pool was allocated for
+        std::vector<void*> allocs;
+        void* pool_view = nullptr;     // host copy of WfPool<R>
+        uint32_t* queue[2] = {nullptr, nullptr};
+        rt::WfCounters* d_ctr = nullptr;
+        rt::WfCounters* h_ctr = nullptr;   // pinned
+        double* sample_L = nullptr;
+        size_t sample_L_bytes = 0;
+        double* acc = nullptr;
+        size_t acc_bytes = 0;
+        std::vector<hipEvent_t> events;
+    } wf;
 };
 
 namespace rt {
@@ -405,6 +423,189 @@ int render_typed(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, const 
     return RT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wavefront pipeline driver
+// ---------------------------------------------------------------------------------------------
+static uint32_t env_u32(const char* name, uint32_t dflt) {
+    const char* v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    return uint32_t(std::strtoul(v, nullptr, 10));
+}
+
+template <typename R>
+int wf_ensure(RtScene* s, uint32_t capacity) {
+    RtScene::Wavefront& w = s->wf;
+    if (w.capacity == capacity && w.real_size == sizeof(R)) return RT_OK;
+    for (void* p : w.allocs) (void)hipFree(p);
+    w.allocs.clear();
+    ::operator delete(w.pool_view);
+    w.pool_view = nullptr;
+    auto* pool = new WfPool<R>();
+    w.pool_view = pool;
+    pool->capacity = capacity;
+    auto alloc = [&](size_t bytes, void** out) -> int {
+        HIP_TRY(hipMalloc(out, bytes));
+        w.allocs.push_back(*out);
+        return RT_OK;
+    };
+    R** reals[] = {&pool->ox, &pool->oy, &pool->oz, &pool->dx, &pool->dy, &pool->dz, &pool->tr, &pool->tg, &pool->tb,
+                   &pool->lr, &pool->lg, &pool->lb, &pool->ht, &pool->hu, &pool->hv};
+    for (R** r : reals)
+        if (int st = alloc(size_t(capacity) * sizeof(R), reinterpret_cast<void**>(r))) return st;
+    if (int st = alloc(size_t(capacity) * 8, reinterpret_cast<void**>(&pool->rng))) return st;
+    if (int st = alloc(size_t(capacity) * 8, reinterpret_cast<void**>(&pool->sample))) return st;
+    if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->depth))) return st;
+    if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->hpc))) return st;
+    if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->htri))) return st;
+    for (int q = 0; q < 2; q++) {
+        if (w.queue[q]) (void)hipFree(w.queue[q]);
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.queue[q]), size_t(capacity) * 4));
+    }
+    if (!w.d_ctr) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.d_ctr), sizeof(WfCounters)));
+    if (!w.h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w.h_ctr), sizeof(WfCounters)));
+    if (w.events.empty()) {
+        w.events.resize(64);
+        for (auto& e : w.events) HIP_TRY(hipEventCreate(&e));
+    }
+    w.capacity = capacity;
+    w.real_size = sizeof(R);
+    return RT_OK;
+}
+
+template <typename R>
+int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, const RtRenderParams& p, uint32_t owned,
+                     double* d_out, hipStream_t stream) {
+    CameraView<R> cv = make_camera_view<R>(cam, p);
+    ParamsView<R> pv = make_params_view<R>(p, owned);
+    const uint64_t npix = uint64_t(cam.image_width) * owned;
+    const uint32_t strata = p.sqrt_spt * p.sqrt_spt;
+    const uint32_t T = p.thread_count;
+    const uint64_t per_replica = uint64_t(strata) * npix;
+    // pool size: enough paths to keep every CU busy for several rounds per launch
+    uint32_t capacity = env_u32("RT_WF_POOL", 1u << 23);  // 8M paths (~1.4 GB of f64 state): measured +10 % over 2M
+    if (uint64_t(capacity) > per_replica * T) capacity = uint32_t(per_replica * T);
+    if (capacity < 64) capacity = 64;
+    if (int st = wf_ensure<R>(s, capacity)) return st;
+    RtScene::Wavefront& w = s->wf;
+    WfPool<R> pool = *static_cast<WfPool<R>*>(w.pool_view);
+
+    // per-sample radiance buffer: as many replicas per group as the memory budget allows
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    size_t budget = size_t(env_u32("RT_WF_SAMPLE_GB", 64)) << 30;
+    size_t avail = free_b + w.sample_L_bytes;
+    if (budget > avail / 2) budget = avail / 2;
+    uint64_t bytes_per_replica = per_replica * 24ull;
+    uint32_t group = uint32_t(std::min<uint64_t>(T, std::max<uint64_t>(1, budget / bytes_per_replica)));
+    if (bytes_per_replica > avail) return set_err(RT_E_NOMEM, "per-sample radiance buffer of one replica does not fit in device memory");
+    size_t need = size_t(bytes_per_replica) * group;
+    if (w.sample_L_bytes < need) {
+        if (w.sample_L) (void)hipFree(w.sample_L);
+        w.sample_L = nullptr;
+        w.sample_L_bytes = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.sample_L), need));
+        w.sample_L_bytes = need;
+    }
+    const bool multi_group = group < T;
+    if (multi_group && w.acc_bytes < npix * 24) {
+        if (w.acc) (void)hipFree(w.acc);
+        w.acc = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.acc), npix * 24));
+        w.acc_bytes = npix * 24;
+    }
+
+    const size_t lds = size_t(ds.view.stack_entries) * 256 * sizeof(int);
+    if (lds > 160 * 1024) return set_err(RT_E_UNSUPPORTED, "mesh BVH too deep for the LDS traversal stack");
+    int n_cu = 0, blocks_per_cu = 0;
+    HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->device));
+    const bool stats = p.collect_stats != 0;
+    if (stats) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_intersect<R, true>, 256, lds));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_intersect<R, false>, 256, lds));
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    const uint32_t isect_blocks = uint32_t(n_cu) * uint32_t(blocks_per_cu);
+    const uint32_t refill_min = env_u32("RT_WF_REFILL", 32);  // measured optimum (64 = no refill: -20 %)
+    const uint32_t check_every = env_u32("RT_WF_CHECK", 8);
+
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), stream));
+    HIP_TRY(hipEventRecord(s->ev0, stream));
+    double isect_ms = 0.0;
+    uint32_t isect_launches = 0;
+    for (uint32_t t0 = 0; t0 < T; t0 += group) {
+        uint32_t nrep = std::min(group, T - t0);
+        WfGroup<R> grp{};
+        grp.total = per_replica * nrep;
+        grp.npix = npix;
+        grp.tid0 = t0;
+        grp.strata = strata;
+        uint32_t first = uint32_t(std::min<uint64_t>(capacity, grp.total));
+        WfCounters init{};
+        init.n_in = first;
+        init.n_out = 0;
+        init.cursor = 0;
+        init.next_sample = first;
+        *w.h_ctr = init;
+        HIP_TRY(hipMemcpyAsync(w.d_ctr, w.h_ctr, sizeof(WfCounters), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL((k_wf_generate<R>), dim3((first + 255) / 256), dim3(256), 0, stream, pool, first, grp, cv, pv, w.queue[0]);
+        int qi = 0;
+        uint32_t upper = first;  // upper bound of the queue length (never grows: slots are reused in place)
+        for (;;) {
+            size_t ev = 0;
+            for (uint32_t k = 0; k < check_every; k++) {
+                HIP_TRY(hipEventRecord(w.events[ev++], stream));
+                if (stats)
+                    hipLaunchKernelGGL((k_wf_intersect<R, true>), dim3(isect_blocks), dim3(256), lds, stream, ds.view, pool, w.queue[qi], w.d_ctr, s->d_counters, refill_min);
+                else
+                    hipLaunchKernelGGL((k_wf_intersect<R, false>), dim3(isect_blocks), dim3(256), lds, stream, ds.view, pool, w.queue[qi], w.d_ctr, s->d_counters, refill_min);
+                HIP_TRY(hipEventRecord(w.events[ev++], stream));
+                if (stats)
+                    hipLaunchKernelGGL((k_wf_shade<R, true>), dim3((upper + 255) / 256), dim3(256), 0, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters);
+                else
+                    hipLaunchKernelGGL((k_wf_shade<R, false>), dim3((upper + 255) / 256), dim3(256), 0, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters);
+                hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(1), 0, stream, w.d_ctr);
+                qi ^= 1;
+                isect_launches++;
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(w.h_ctr, w.d_ctr, sizeof(WfCounters), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            for (size_t e = 0; e + 1 < ev; e += 2) {
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, w.events[e], w.events[e + 1]));
+                isect_ms += ms;
+            }
+            upper = w.h_ctr->n_in;
+            if (upper == 0) break;
+        }
+        hipLaunchKernelGGL(k_wf_resolve, dim3(uint32_t((npix + 255) / 256)), dim3(256), 0, stream, w.sample_L, w.acc, npix, strata, nrep,
+                           pv.spp, int(t0 == 0), d_out, int(t0 + nrep >= T));
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev1, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    DeviceCounters hc{};
+    HIP_TRY(hipMemcpy(&hc, s->d_counters, sizeof hc, hipMemcpyDeviceToHost));
+    RtRenderStats& st = s->stats;
+    st = RtRenderStats{};
+    st.kernel_ms = ms;
+    st.traversal_kernel_ms = isect_ms;
+    st.n_launches = isect_launches;
+    st.pipeline_used = RT_PIPELINE_WAVEFRONT;
+    st.samples = npix * uint64_t(pv.spp);
+    st.rays = hc.rays;
+    st.mesh_rays = hc.mesh_rays;
+    st.node_visits = hc.node_visits;
+    st.tri_tests = hc.tri_tests;
+    st.prim_tests = hc.prim_tests;
+    st.bytes_node = sizeof(BvhNode<R>);
+    st.bytes_tri = sizeof(TriRec<R>);
+    st.bytes_attr = sizeof(TriAttr<R>);
+    // path state read by intersect (ray 6R) + written (hit 3R + 8) and read+written by shade per ray
+    st.bytes_state = 6 * sizeof(R) + 3 * sizeof(R) + 8 + 4;
+    return RT_OK;
+}
+
 static int validate_render_args(const RtCameraDesc* camera, const RtRenderParams* params) {
     if (params->sqrt_spt == 0 || params->thread_count == 0) return set_err(RT_E_INVALID, "sqrt_spt and thread_count must be positive");
     if (params->band_rows != 0 && params->n_parts > 1 && params->part >= params->n_parts) return set_err(RT_E_INVALID, "part >= n_parts");
@@ -462,6 +663,15 @@ void rt_scene_destroy(RtScene* s) {
     (void)hipSetDevice(s->device);
     s->f64.reset();
     s->f32.reset();
+    for (void* p : s->wf.allocs) (void)hipFree(p);
+    if (s->wf.queue[0]) (void)hipFree(s->wf.queue[0]);
+    if (s->wf.queue[1]) (void)hipFree(s->wf.queue[1]);
+    if (s->wf.d_ctr) (void)hipFree(s->wf.d_ctr);
+    if (s->wf.h_ctr) (void)hipHostFree(s->wf.h_ctr);
+    if (s->wf.sample_L) (void)hipFree(s->wf.sample_L);
+    if (s->wf.acc) (void)hipFree(s->wf.acc);
+    for (hipEvent_t e : s->wf.events) (void)hipEventDestroy(e);
+    ::operator delete(s->wf.pool_view);
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -484,7 +694,10 @@ int rt_render_device(const RtScene* scene, const RtCameraDesc* camera, const RtR
     uint32_t owned = owned_rows(camera->image_height, params);
     if (owned == 0) return RT_OK;
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
-    if (params->pipeline == RT_PIPELINE_WAVEFRONT) return set_err(RT_E_UNSUPPORTED, "wavefront pipeline not built yet");
+    // AUTO: the wavefront scheduler when the scene has triangle meshes, the megakernel otherwise
+    bool has_mesh = !s->compiled.meshes.empty();
+    bool wavefront = params->pipeline == RT_PIPELINE_WAVEFRONT || (params->pipeline == RT_PIPELINE_AUTO && has_mesh);
+    if (params->max_depth == 0) wavefront = false;  // every sample is black (camera.rs:290): nothing to schedule
     if (params->precision == RT_PRECISION_F32) {
         if (!s->f32) {
             auto ds = std::make_unique<DeviceScene<float>>();
@@ -492,6 +705,7 @@ int rt_render_device(const RtScene* scene, const RtCameraDesc* camera, const RtR
             if (r != RT_OK) return r;
             s->f32 = std::move(ds);
         }
+        if (wavefront) return render_wavefront<float>(s, *s->f32, *camera, *params, owned, d_rgba_out, st);
         return render_typed<float>(s, *s->f32, *camera, *params, owned, d_rgba_out, st);
     }
     if (!s->f64) {
@@ -500,6 +714,7 @@ int rt_render_device(const RtScene* scene, const RtCameraDesc* camera, const RtR
         if (r != RT_OK) return r;
         s->f64 = std::move(ds);
     }
+    if (wavefront) return render_wavefront<double>(s, *s->f64, *camera, *params, owned, d_rgba_out, st);
     return render_typed<double>(s, *s->f64, *camera, *params, owned, d_rgba_out, st);
 }
 

@@ -1,0 +1,412 @@
+// rt_wavefront.h — iterative wavefront scheduler (included by rt_kernels.hip).
+//
+// The reference's recursion `ray_color -> world.test -> scatter -> ray_color` (camera.rs:282-332)
+// becomes a loop over a POOL of paths kept in HBM as structure-of-arrays:
+//
+//   k_wf_generate   camera rays for the first P samples                       (camera.rs:260-280)
+//   repeat until no path is alive:
+//     k_wf_intersect   closest hit of every queued path: persistent waves pull rays from the
+//                      queue with one wave-aggregated atomic and REFILL idle lanes while the
+//                      other lanes are still walking the BVH (per-lane stack in LDS)
+//     k_wf_shade       emission / scatter / light-biased mixture pdf for every hit; a path that
+//                      ends writes its radiance to the per-sample buffer and restarts IN PLACE
+//                      on the next unrendered sample; surviving slots are compacted into the
+//                      next queue with ballot + mbcnt prefix sums (one atomic per wave)
+//   k_wf_resolve    per pixel: sum the sample radiances in the reference's order
+//                   (replica, sy, sx: camera.rs:217-229, 247-253) -> frame
+//
+// Every sample owns one slot of the per-sample radiance buffer (24 B), so the frame does not
+// depend on scheduling: bit-identical between runs, partitions and pipelines.
+#pragma once
+#include "rt_device.h"
+
+namespace rt {
+
+template <typename R>
+struct WfPool {
+    uint32_t capacity;
+    R *ox, *oy, *oz, *dx, *dy, *dz;  // current ray, world space
+    R *tr, *tg, *tb;                 // throughput T_k
+    R *lr, *lg, *lb;                 // radiance accumulated so far
+    uint64_t* rng;                   // stream state
+    uint64_t* sample;                // sample index within the current replica group
+    uint32_t* depth;                 // remaining depth (the `depth` argument of ray_color)
+    R *ht, *hu, *hv;                 // closest hit: t, (u, v)
+    int32_t *hpc, *htri;             // op that produced it (-1 none), triangle slot
+};
+
+struct WfCounters {
+    uint32_t n_in;        // entries of the current queue
+    uint32_t n_out;       // entries appended to the next queue
+    uint32_t cursor;      // next queue entry to hand out (intersect kernel)
+    uint32_t _pad;
+    unsigned long long next_sample;  // next sample (within the group) to start
+};
+
+// Sample s of a replica group -> (replica, stratum, owned pixel).  Pixels run fastest so that a
+// wave starts 64 neighbouring pixels of one stratum: coherent primary rays, coalesced buffers.
+template <typename R>
+struct WfGroup {
+    uint64_t total;      // samples in this group = n_replicas * S*S * npix
+    uint64_t npix;       // owned pixels
+    uint32_t tid0;       // first replica of the group
+    uint32_t strata;     // S*S
+};
+
+template <typename R>
+RT_DEV void wf_start_sample(const WfPool<R>& pool, uint32_t slot, uint64_t s, const WfGroup<R>& grp,
+                            const CameraView<R>& cam, const ParamsView<R>& prm) {
+    uint64_t per_replica = uint64_t(grp.strata) * grp.npix;
+    uint32_t tid_local = uint32_t(s / per_replica);
+    uint64_t rem = s - uint64_t(tid_local) * per_replica;
+    uint32_t st = uint32_t(rem / grp.npix);
+    uint64_t pix = rem - uint64_t(st) * grp.npix;
+    uint32_t row = uint32_t(pix / cam.width), px = uint32_t(pix - uint64_t(row) * cam.width);
+    uint32_t py;
+    if (prm.band_rows == 0 || prm.n_parts <= 1) py = row;
+    else py = ((row / prm.band_rows) * prm.n_parts + prm.part) * prm.band_rows + (row % prm.band_rows);
+    uint32_t S = cam.sqrt_spt;
+    uint32_t sy = st / S, sx = st - sy * S;
+    Rng rng;
+    rng.key(prm.seed, grp.tid0 + tid_local, uint64_t(py) * cam.width + px, st);
+    Ray<R> ray = get_ray(cam, px, py, sx, sy, rng);
+    pool.ox[slot] = ray.o.x; pool.oy[slot] = ray.o.y; pool.oz[slot] = ray.o.z;
+    pool.dx[slot] = ray.d.x; pool.dy[slot] = ray.d.y; pool.dz[slot] = ray.d.z;
+    pool.tr[slot] = R(1); pool.tg[slot] = R(1); pool.tb[slot] = R(1);
+    pool.lr[slot] = R(0); pool.lg[slot] = R(0); pool.lb[slot] = R(0);
+    pool.rng[slot] = rng.s;
+    pool.sample[slot] = s;
+    pool.depth[slot] = cam.max_depth;
+}
+
+template <typename R>
+__global__ void __launch_bounds__(256) k_wf_generate(WfPool<R> pool, uint32_t count, WfGroup<R> grp, CameraView<R> cam,
+                                                     ParamsView<R> prm, uint32_t* __restrict__ queue) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    wf_start_sample(pool, i, uint64_t(i), grp, cam, prm);
+    queue[i] = i;
+}
+
+// Number of lanes below `lane` whose bit is set in `mask` (v_mbcnt_lo/hi).
+RT_DEV uint32_t lane_prefix(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Intersect: world.test for every queued path.  Persistent waves; each lane is a small state
+// machine (scene program counter + BVH traversal state), idle lanes are refilled from the queue.
+// ---------------------------------------------------------------------------------------------
+template <typename R, bool STATS>
+__global__ void __launch_bounds__(256) k_wf_intersect(SceneView<R> sc, WfPool<R> pool, const uint32_t* __restrict__ queue,
+                                                      WfCounters* __restrict__ ctr, DeviceCounters* counters, uint32_t refill_min) {
+    extern __shared__ int lds_stack[];
+    int* stack = lds_stack + threadIdx.x;
+    const int stride = int(blockDim.x);
+    const uint32_t n = ctr->n_in;
+    const uint32_t lane = threadIdx.x & 63u;
+    const R t_lo = R(0.001);
+
+    LaneCounters cnt;
+    bool has = false;        // this lane holds a ray
+    bool in_mesh = false;    // ... and is inside a mesh BVH
+    bool exhausted = false;  // wave-uniform: the queue has been handed out completely
+    uint32_t slot = 0;
+    Ray<R> wray{}, cur{};
+    Best<R> best{};
+    int32_t pc = 0;
+    // mesh traversal state
+    int32_t node = 0;
+    int sp = 0;
+    V3<R> inv{}, oi{};
+    const BvhNode<R>* nodes = nullptr;
+    const TriRec<R>* tris = nullptr;
+    uint32_t tri_base = 0;
+    bool hit_back = false;
+
+    for (;;) {
+        // ---- refill idle lanes ----
+        unsigned long long idle = __ballot(!has);
+        uint32_t n_idle = uint32_t(__popcll(idle));
+        if (!exhausted && n_idle >= refill_min) {
+            uint32_t base = 0;
+            int leader = __ffsll((long long)idle) - 1;
+            if (int(lane) == leader) base = atomicAdd(&ctr->cursor, n_idle);
+            base = __shfl(base, leader);
+            if (base + n_idle >= n) exhausted = true;
+            uint32_t my = base + lane_prefix(idle);
+            if (!has && my < n) {
+                slot = queue[my];
+                wray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
+                cur = wray;
+                best.t = Lim<R>::inf(); best.pc = -1; best.tri = -1; best.u = R(0); best.v = R(0);
+                pc = 0;
+                has = true;
+                in_mesh = false;
+                if (STATS) cnt.rays++;
+            }
+        }
+        if (__ballot(has) == 0ull) {
+            if (exhausted) break;
+            continue;  // nothing held but the queue may still have entries: fetch again
+        }
+        // ---- scene program until the next mesh (or the end) ----
+        if (has && !in_mesh) {
+            for (;;) {
+                const Op op = sc.ops[pc];
+                if (op.type == OP_END) {
+                    pool.ht[slot] = best.t; pool.hu[slot] = best.u; pool.hv[slot] = best.v;
+                    pool.hpc[slot] = best.pc; pool.htri[slot] = best.tri;
+                    has = false;
+                    break;
+                }
+                if (op.type == OP_MESH) {
+                    const MeshInst& mi = sc.meshes[op.arg];
+                    nodes = sc.nodes + mi.node_base;
+                    tris = sc.tris + mi.tri_base;
+                    tri_base = mi.tri_base;
+                    hit_back = (mi.flags & RT_MESH_HIT_BACK_FACES) != 0;
+                    const R big = sizeof(R) == 8 ? R(1e150) : R(1e18);  // see mesh_traverse
+                    inv = {fabs(cur.inv.x) > big ? copysign(big, cur.inv.x) : cur.inv.x,
+                           fabs(cur.inv.y) > big ? copysign(big, cur.inv.y) : cur.inv.y,
+                           fabs(cur.inv.z) > big ? copysign(big, cur.inv.z) : cur.inv.z};
+                    oi = cur.o * inv;
+                    node = 0;
+                    sp = 0;
+                    in_mesh = true;
+                    if (STATS) cnt.mesh_rays++;
+                    break;
+                }
+                switch (op.type) {
+                    case OP_BOUNDS:
+                        if (!test_bounding_box(sc.bounds[op.arg], cur, t_lo, best.t)) {
+                            pc = op.skip;
+                            continue;
+                        }
+                        break;
+                    case OP_XFORM_PUSH: {
+                        const Xform<R>& x = sc.xforms[op.arg];
+                        cur = make_ray(xform_apply(x.inv, cur.o, R(1)), xform_apply(x.inv, cur.d, R(0)));
+                        break;
+                    }
+                    case OP_XFORM_POP:
+                        cur = ray_in_chain(sc, wray, op.chain);
+                        break;
+                    case OP_SPHERE: {
+                        R t;
+                        if (STATS) cnt.prim_tests++;
+                        if (sphere_test(sc.spheres[op.arg], cur, t_lo, best.t, t)) { best.t = t; best.pc = pc; }
+                        break;
+                    }
+                    case OP_PLANE: {
+                        R t, u, v;
+                        if (STATS) cnt.prim_tests++;
+                        if (plane_test(sc.planes[op.arg], cur, t_lo, best.t, t, u, v)) { best.t = t; best.pc = pc; best.u = u; best.v = v; }
+                        break;
+                    }
+                    case OP_SKY:
+                        if (STATS) cnt.prim_tests++;
+                        if (!(Lim<R>::inf() > best.t)) { best.t = Lim<R>::inf(); best.pc = pc; }
+                        break;
+                    case OP_SUN: {
+                        if (STATS) cnt.prim_tests++;
+                        const SunPrim<R>& s = sc.suns[op.arg];
+                        V3<R> unit_dir = to_unit(cur.d);
+                        if (!(fabs(dot(ld3(s.direction), unit_dir) - R(1)) > R(0.001)) && !(Lim<R>::max() >= best.t)) {
+                            best.t = Lim<R>::max();
+                            best.pc = pc;
+                        }
+                        break;
+                    }
+                    default: break;
+                }
+                pc++;
+            }
+        }
+        // ---- BVH traversal: all lanes inside a mesh step together until too few remain ----
+        while (true) {
+            unsigned long long walking = __ballot(in_mesh);
+            if (walking == 0ull) break;
+            if (in_mesh) {
+                bool pop = true;
+                if (node >= 0) {
+                    const BvhNode<R>& nd = nodes[node];
+                    if (STATS) cnt.node_visits++;
+                    R t0x = nd.lo0[0] * inv.x - oi.x, t1x = nd.hi0[0] * inv.x - oi.x;
+                    R t0y = nd.lo0[1] * inv.y - oi.y, t1y = nd.hi0[1] * inv.y - oi.y;
+                    R t0z = nd.lo0[2] * inv.z - oi.z, t1z = nd.hi0[2] * inv.z - oi.z;
+                    R near0 = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmax(fmin(t0z, t1z), t_lo));
+                    R far0 = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmin(fmax(t0z, t1z), best.t));
+                    R s0x = nd.lo1[0] * inv.x - oi.x, s1x = nd.hi1[0] * inv.x - oi.x;
+                    R s0y = nd.lo1[1] * inv.y - oi.y, s1y = nd.hi1[1] * inv.y - oi.y;
+                    R s0z = nd.lo1[2] * inv.z - oi.z, s1z = nd.hi1[2] * inv.z - oi.z;
+                    R near1 = fmax(fmax(fmin(s0x, s1x), fmin(s0y, s1y)), fmax(fmin(s0z, s1z), t_lo));
+                    R far1 = fmin(fmin(fmax(s0x, s1x), fmax(s0y, s1y)), fmin(fmax(s0z, s1z), best.t));
+                    int32_t c0 = nd.c0, c1 = nd.c1;
+                    bool h0 = (near0 <= far0) && c0 != kEmptyChild;
+                    bool h1 = (near1 <= far1) && c1 != kEmptyChild;
+                    if (h0 && h1) {
+                        bool first0 = near0 <= near1;
+                        stack[sp * stride] = first0 ? c1 : c0;
+                        sp++;
+                        node = first0 ? c0 : c1;
+                        pop = false;
+                    } else if (h0) { node = c0; pop = false; }
+                    else if (h1) { node = c1; pop = false; }
+                } else {
+                    uint32_t code = uint32_t(~node);
+                    uint32_t first = code >> 3, count = (code & 7u) + 1u;
+                    for (uint32_t i = 0; i < count; i++) {
+                        const TriRec<R>& tr = tris[first + i];
+                        if (STATS) cnt.tri_tests++;
+                        V3<R> edge1 = ld3(tr.e1), edge2 = ld3(tr.e2);
+                        V3<R> ray_x_edge2 = cross(cur.d, edge2);
+                        R det = dot(edge1, ray_x_edge2);
+                        R dd = hit_back ? fabs(det) : det;
+                        if (dd < Lim<R>::eps()) continue;
+                        R inv_det = R(1) / det;
+                        V3<R> b = cur.o - ld3(tr.v0);
+                        R u = dot(b, ray_x_edge2) * inv_det;
+                        if (u < R(0) || u > R(1)) continue;
+                        V3<R> b_x_edge1 = cross(b, edge1);
+                        R v = dot(cur.d, b_x_edge1) * inv_det;
+                        if (v < R(0) || u + v > R(1)) continue;
+                        R t = dot(edge2, b_x_edge1) * inv_det;
+                        if (t <= t_lo || best.t <= t) continue;
+                        best.t = t; best.pc = pc; best.tri = int32_t(tri_base + first + i); best.u = u; best.v = v;
+                    }
+                }
+                if (pop) {
+                    if (sp == 0) { in_mesh = false; pc++; }
+                    else { sp--; node = stack[sp * stride]; }
+                }
+            }
+            // leave the traversal loop when enough lanes could do other work (finish / refill)
+            uint32_t still = uint32_t(__popcll(__ballot(in_mesh)));
+            if (still == 0u) break;
+            if (!exhausted && 64u - still >= refill_min) break;
+        }
+    }
+    if (STATS) {
+        atomicAdd(&counters->rays, (unsigned long long)cnt.rays);
+        atomicAdd(&counters->mesh_rays, (unsigned long long)cnt.mesh_rays);
+        atomicAdd(&counters->node_visits, (unsigned long long)cnt.node_visits);
+        atomicAdd(&counters->tri_tests, (unsigned long long)cnt.tri_tests);
+        atomicAdd(&counters->prim_tests, (unsigned long long)cnt.prim_tests);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shade: one path vertex per lane (camera.rs:295-331), regeneration and queue compaction.
+// ---------------------------------------------------------------------------------------------
+template <typename R, bool STATS>
+__global__ void __launch_bounds__(256) k_wf_shade(SceneView<R> sc, CameraView<R> cam, ParamsView<R> prm, WfPool<R> pool, WfGroup<R> grp,
+                                                  const uint32_t* __restrict__ queue_in, uint32_t* __restrict__ queue_out,
+                                                  WfCounters* __restrict__ ctr, double* __restrict__ sample_L, DeviceCounters* counters) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = ctr->n_in;
+    const uint32_t lane = threadIdx.x & 63u;
+    bool active = i < n;
+    bool alive = false;
+    uint32_t slot = 0;
+    LaneCounters cnt;
+    if (active) {
+        slot = queue_in[i];
+        PathState<R> ps;
+        ps.ray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
+        ps.throughput = mk<R>(pool.tr[slot], pool.tg[slot], pool.tb[slot]);
+        ps.radiance = mk<R>(pool.lr[slot], pool.lg[slot], pool.lb[slot]);
+        ps.depth = pool.depth[slot];
+        Best<R> best;
+        best.t = pool.ht[slot]; best.u = pool.hu[slot]; best.v = pool.hv[slot];
+        best.pc = pool.hpc[slot]; best.tri = pool.htri[slot];
+        Rng rng;
+        rng.s = pool.rng[slot];
+        bool cont = shade<R, STATS>(sc, prm, ps, best, rng, cnt);
+        ps.depth--;
+        if (cont && ps.depth != 0) {  // depth == 0: ray_color returns black without tracing (camera.rs:290)
+            pool.ox[slot] = ps.ray.o.x; pool.oy[slot] = ps.ray.o.y; pool.oz[slot] = ps.ray.o.z;
+            pool.dx[slot] = ps.ray.d.x; pool.dy[slot] = ps.ray.d.y; pool.dz[slot] = ps.ray.d.z;
+            pool.tr[slot] = ps.throughput.x; pool.tg[slot] = ps.throughput.y; pool.tb[slot] = ps.throughput.z;
+            pool.lr[slot] = ps.radiance.x; pool.lg[slot] = ps.radiance.y; pool.lb[slot] = ps.radiance.z;
+            pool.rng[slot] = rng.s;
+            pool.depth[slot] = ps.depth;
+            alive = true;
+        } else {
+            uint64_t s = pool.sample[slot];
+            sample_L[3 * s + 0] = double(ps.radiance.x);
+            sample_L[3 * s + 1] = double(ps.radiance.y);
+            sample_L[3 * s + 2] = double(ps.radiance.z);
+        }
+    }
+    // ---- regenerate: finished paths restart in place on the next samples ----
+    unsigned long long want = __ballot(active && !alive);
+    if (want) {
+        uint32_t n_want = uint32_t(__popcll(want));
+        unsigned long long base = 0;
+        int leader = __ffsll((long long)want) - 1;
+        if (int(lane) == leader) base = atomicAdd(&ctr->next_sample, (unsigned long long)n_want);
+        base = __shfl(base, leader);
+        if (active && !alive) {
+            unsigned long long s = base + lane_prefix(want);
+            if (s < grp.total) {
+                wf_start_sample(pool, slot, s, grp, cam, prm);
+                alive = true;
+            }
+        }
+    }
+    // ---- compact surviving slots into the next queue ----
+    unsigned long long keep = __ballot(alive);
+    if (keep) {
+        uint32_t n_keep = uint32_t(__popcll(keep));
+        uint32_t base = 0;
+        int leader = __ffsll((long long)keep) - 1;
+        if (int(lane) == leader) base = atomicAdd(&ctr->n_out, n_keep);
+        base = __shfl(base, leader);
+        if (alive) queue_out[base + lane_prefix(keep)] = slot;
+    }
+    if (STATS) {
+        unsigned long long pt = cnt.prim_tests;
+        if (pt) atomicAdd(&counters->prim_tests, pt);
+    }
+}
+
+// Rotates the queue counters between iterations (device side, no host round trip).
+__global__ void k_wf_advance(WfCounters* ctr) {
+    ctr->n_in = ctr->n_out;
+    ctr->n_out = 0;
+    ctr->cursor = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Resolve: ordered sums.  sample_L is indexed by the sample number s = ((tid_local * S*S + st) * npix + pix).
+// acc[pix] += (sum_st L) / spp for every replica of the group, in replica order (camera.rs:229,247-253).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_wf_resolve(const double* __restrict__ sample_L, double* __restrict__ acc, uint64_t npix,
+                                                    uint32_t strata, uint32_t n_replicas, double spp, int first_group,
+                                                    double* __restrict__ out, int last_group) {
+    uint64_t pix = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (pix >= npix) return;
+    double a[3];
+    for (int k = 0; k < 3; k++) a[k] = first_group ? 0.0 : acc[3 * pix + k];
+    for (uint32_t t = 0; t < n_replicas; t++) {
+        double col[3] = {0.0, 0.0, 0.0};
+        for (uint32_t st = 0; st < strata; st++) {
+            uint64_t s = (uint64_t(t) * strata + st) * npix + pix;
+            col[0] += sample_L[3 * s + 0];
+            col[1] += sample_L[3 * s + 1];
+            col[2] += sample_L[3 * s + 2];
+        }
+        for (int k = 0; k < 3; k++) a[k] += col[k] / spp;
+    }
+    if (last_group) {
+        out[4 * pix + 0] = a[0];
+        out[4 * pix + 1] = a[1];
+        out[4 * pix + 2] = a[2];
+        out[4 * pix + 3] = 0.0;
+    } else {
+        for (int k = 0; k < 3; k++) acc[3 * pix + k] = a[k];
+    }
+}
+
+}  // namespace rt

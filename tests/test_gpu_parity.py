@@ -56,14 +56,39 @@ def assert_f64_parity(gpu, ref):
     assert np.all(gpu[..., 3] == 0.0)
 
 
+PIPELINES = {"mega": api.RT_PIPELINE_MEGAKERNEL, "wavefront": api.RT_PIPELINE_WAVEFRONT}
+
+
+@pytest.mark.parametrize("pipeline", sorted(PIPELINES))
 @pytest.mark.parametrize("name", sorted(SCENES))
-def test_f64_matches_oracle(dev, name):
+def test_f64_matches_oracle(dev, name, pipeline):
+    """Both schedulers (per-pixel megakernel, wavefront pool) against the oracle."""
     hs = api.HostScene(SCENES[name])
     ref, _ = pyoracle.render(hs.desc, hs.camera, hs.params)
     scene = api.DeviceScene(hs.desc, 0)
-    gpu = scene.render(hs.camera, hs.params)
+    p = hs.params.copy()
+    p.pipeline = PIPELINES[pipeline]
+    gpu = scene.render(hs.camera, p)
     assert gpu.shape == ref.shape
     assert_f64_parity(gpu, ref)
+    assert scene.stats().pipeline_used == PIPELINES[pipeline]
+
+
+def test_pipelines_are_bit_identical_and_small_pool_works(dev, monkeypatch):
+    """The wavefront scheduler writes every sample to its own slot and sums in the reference's
+    order, so its frame equals the megakernel's bit for bit — whatever the pool size, including a
+    pool far smaller than the sample count (many regenerations) and replica groups."""
+    hs = api.HostScene(["scenes/light_test", "-w=80", "-s=48", "-t=3", "--seed=13"])
+    scene = api.DeviceScene(hs.desc, 0)
+    p = hs.params.copy()
+    p.pipeline = api.RT_PIPELINE_MEGAKERNEL
+    mega = scene.render(hs.camera, p)
+    p.pipeline = api.RT_PIPELINE_WAVEFRONT
+    np.testing.assert_array_equal(scene.render(hs.camera, p), mega)
+    monkeypatch.setenv("RT_WF_POOL", "1000")
+    np.testing.assert_array_equal(scene.render(hs.camera, p), mega)
+    monkeypatch.setenv("RT_WF_REFILL", "64")
+    np.testing.assert_array_equal(scene.render(hs.camera, p), mega)
 
 
 @pytest.mark.parametrize("name", sorted(GOLD.files))
@@ -98,6 +123,12 @@ def test_stats_counters_and_collect_flag(dev):
     assert st.samples == hs.width * hs.height * hs.spp
     assert st.rays >= st.samples and st.mesh_rays > 0 and st.node_visits > st.mesh_rays and st.tri_tests > 0
     assert st.kernel_ms > 0 and st.bytes_node == 128 and st.bytes_tri == 80
+    assert st.pipeline_used == api.RT_PIPELINE_WAVEFRONT     # AUTO picks the wavefront scheduler for mesh scenes
+    q = p.copy()
+    q.pipeline = api.RT_PIPELINE_MEGAKERNEL
+    scene.render(hs.camera, q)
+    sm = scene.stats()
+    assert (sm.rays, sm.node_visits, sm.tri_tests, sm.prim_tests) == (st.rays, st.node_visits, st.tri_tests, st.prim_tests)
     p.collect_stats = 0
     np.testing.assert_array_equal(scene.render(hs.camera, p), with_stats)   # counting never changes pixels
     _, ost = pyoracle.render(hs.desc, hs.camera, hs.params)

@@ -9,15 +9,17 @@ def compare(args, label):
     hs = api.HostScene(args)
     t = time.time(); ref, ost = pyoracle.render(hs.desc, hs.camera, hs.params); to = time.time() - t
     ds = api.DeviceScene(hs.desc, 0)
-    for prec, name in ((api.RT_PRECISION_F64, "f64"), (api.RT_PRECISION_F32, "f32")):
-        p = hs.params.copy(); p.precision = prec; p.collect_stats = 1
+    for prec, name, pipe in ((api.RT_PRECISION_F64, "f64", api.RT_PIPELINE_MEGAKERNEL), (api.RT_PRECISION_F64, "f64", api.RT_PIPELINE_WAVEFRONT),
+                             (api.RT_PRECISION_F32, "f32", api.RT_PIPELINE_WAVEFRONT)):
+        p = hs.params.copy(); p.precision = prec; p.collect_stats = 1; p.pipeline = pipe
+        name = name + ("-wf" if pipe == api.RT_PIPELINE_WAVEFRONT else "-mega")
         t = time.time(); img = ds.render(hs.camera, p); tg = time.time() - t
         st = ds.stats()
         a, b = img[..., :3], ref[..., :3]
         both_nan = np.isnan(a) & np.isnan(b)
         d = np.abs(a - b); d[both_nan] = 0
         rel = d / np.maximum(np.abs(b), 1e-3)
-        if name == "f64":
+        if name.startswith("f64"):
             bad = np.argwhere((rel > 1e-6).any(axis=2) | (np.isnan(a) != np.isnan(b)).any(axis=2))
             np.set_printoptions(linewidth=220, precision=6, suppress=True)
             for (yy, xx) in bad[:3]:
@@ -43,3 +45,5 @@ if __name__ == "__main__":
     for sc in sys.argv[1:] or ["sun_sky", "bvh_spheres", "hollow_glass", "nested_transform", "single_light", "sky_only"]:
         compare(["tests/scenes/" + sc, "-s=16", "--seed=2"], sc)
     compare(["-w=96", "-s=16", "--seed=7"], "default")
+    compare(["scenes/light_test", "-w=96", "-s=32", "-t=2", "--seed=3"], "light_test")
+    compare(["scenes/cornell", "-w=64", "-s=16", "--seed=1"], "cornell")
