@@ -157,10 +157,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    kernel_ms = []
+    kernel_ms, launches = [], []
     for _ in range(a.steps):
         step()
-        kernel_ms.append(scene.stats().traversal_kernel_ms)
+        st_ = scene.stats()
+        kernel_ms.append(st_.traversal_kernel_ms)
+        launches.append(max(st_.n_launches, 1))
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -182,20 +184,29 @@ def main():
         nbytes = (counters.node_visits * counters.bytes_node + counters.tri_tests * counters.bytes_tri +
                   counters.mesh_rays * counters.bytes_attr + counters.rays * counters.bytes_state +
                   rows * hs.width * 32)
-        avg_ms = sum(kernel_ms) / len(kernel_ms)
+        # per LAUNCH of the dominant kernel: a step is 1 launch of the megakernel or n launches of
+        # k_wf_intersect (one per wavefront iteration); durations are HIP-event times on the
+        # render stream, summed by the library (RtRenderStats.traversal_kernel_ms / n_launches)
+        n_launch = sum(launches) / len(launches)
+        avg_ms = sum(kernel_ms) / len(kernel_ms) / n_launch
+        nbytes = nbytes / n_launch
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"{a.workload}_{a.precision}")
+                kname = "mega" if counters.pipeline_used == api.RT_PIPELINE_MEGAKERNEL else "wf"
+                traffic = json.load(open(tpath)).get(f"{a.workload}_{a.precision}_{kname}_per_step")
+                if traffic is not None:
+                    traffic = traffic / n_launch
             except Exception:
                 traffic = None
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel": "k_megakernel" if counters.pipeline_used == api.RT_PIPELINE_MEGAKERNEL else "k_wf_intersect",
-            "kernel_ms_avg": avg_ms, "algorithmic_bytes_per_launch": nbytes,
+            "kernel_ms_avg": avg_ms, "launches_per_step": n_launch, "algorithmic_bytes_per_launch": nbytes,
+            "kernel_ms_per_step": avg_ms * n_launch,
             "rays_per_sample": counters.rays / max(counters.samples, 1),
             "node_visits_per_ray": counters.node_visits / counters.rays,
             "tri_tests_per_ray": counters.tri_tests / counters.rays,

@@ -335,6 +335,7 @@ struct RtScene {
         std::vector<void*> allocs;
         void* pool_view = nullptr;     // host copy of WfPool<R>
         uint32_t* queue[2] = {nullptr, nullptr};
+        uint32_t* mesh_queue = nullptr;
         rt::WfCounters* d_ctr = nullptr;
         rt::WfCounters* h_ctr = nullptr;   // pinned
         double* sample_L = nullptr;
@@ -461,6 +462,8 @@ int wf_ensure(RtScene* s, uint32_t capacity) {
         if (w.queue[q]) (void)hipFree(w.queue[q]);
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.queue[q]), size_t(capacity) * 4));
     }
+    if (w.mesh_queue) (void)hipFree(w.mesh_queue);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.mesh_queue), size_t(capacity) * 4));
     if (!w.d_ctr) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.d_ctr), sizeof(WfCounters)));
     if (!w.h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w.h_ctr), sizeof(WfCounters)));
     if (w.events.empty()) {
@@ -482,7 +485,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     const uint32_t T = p.thread_count;
     const uint64_t per_replica = uint64_t(strata) * npix;
     // pool size: enough paths to keep every CU busy for several rounds per launch
-    uint32_t capacity = env_u32("RT_WF_POOL", 1u << 23);  // 8M paths (~1.4 GB of f64 state): measured +10 % over 2M
+    uint32_t capacity = env_u32("RT_WF_POOL", 1u << 24);  // 16M paths (~2.7 GB of f64 state); measured: 2M 260, 8M 350, 16M 362 Msamples/s
     if (uint64_t(capacity) > per_replica * T) capacity = uint32_t(per_replica * T);
     if (capacity < 64) capacity = 64;
     if (int st = wf_ensure<R>(s, capacity)) return st;
@@ -522,8 +525,23 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     if (stats) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_intersect<R, true>, 256, lds));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_intersect<R, false>, 256, lds));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
+    // Scenes whose program has exactly one mesh op use the split intersect (k_wf_prims + k_wf_mesh).
+    int32_t mesh_pc = -1;
+    {
+        int n_mesh_ops = 0;
+        for (size_t i = 0; i < s->compiled.ops.size(); i++)
+            if (s->compiled.ops[i].type == OP_MESH) { n_mesh_ops++; mesh_pc = int32_t(i); }
+        if (n_mesh_ops != 1 || env_u32("RT_WF_SPLIT", 1) == 0) mesh_pc = -1;
+    }
+    const bool split = mesh_pc >= 0;
+    if (split) {
+        if (stats) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_mesh<R, true>, 256, lds));
+        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_mesh<R, false>, 256, lds));
+        if (blocks_per_cu < 1) blocks_per_cu = 1;
+    }
     const uint32_t isect_blocks = uint32_t(n_cu) * uint32_t(blocks_per_cu);
     const uint32_t refill_min = env_u32("RT_WF_REFILL", 32);  // measured optimum (64 = no refill: -20 %)
+    const uint32_t inner_min = env_u32("RT_WF_INNER_MIN", 16);
     const uint32_t check_every = env_u32("RT_WF_CHECK", 8);
 
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), stream));
@@ -542,6 +560,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
         init.n_in = first;
         init.n_out = 0;
         init.cursor = 0;
+        init.n_mesh = 0;
         init.next_sample = first;
         *w.h_ctr = init;
         HIP_TRY(hipMemcpyAsync(w.d_ctr, w.h_ctr, sizeof(WfCounters), hipMemcpyHostToDevice, stream));
@@ -551,12 +570,25 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
         for (;;) {
             size_t ev = 0;
             for (uint32_t k = 0; k < check_every; k++) {
-                HIP_TRY(hipEventRecord(w.events[ev++], stream));
-                if (stats)
-                    hipLaunchKernelGGL((k_wf_intersect<R, true>), dim3(isect_blocks), dim3(256), lds, stream, ds.view, pool, w.queue[qi], w.d_ctr, s->d_counters, refill_min);
-                else
-                    hipLaunchKernelGGL((k_wf_intersect<R, false>), dim3(isect_blocks), dim3(256), lds, stream, ds.view, pool, w.queue[qi], w.d_ctr, s->d_counters, refill_min);
-                HIP_TRY(hipEventRecord(w.events[ev++], stream));
+                if (split) {
+                    if (stats)
+                        hipLaunchKernelGGL((k_wf_prims<R, true>), dim3((upper + 255) / 256), dim3(256), 0, stream, ds.view, pool, w.queue[qi], w.mesh_queue, w.d_ctr, s->d_counters, mesh_pc);
+                    else
+                        hipLaunchKernelGGL((k_wf_prims<R, false>), dim3((upper + 255) / 256), dim3(256), 0, stream, ds.view, pool, w.queue[qi], w.mesh_queue, w.d_ctr, s->d_counters, mesh_pc);
+                    HIP_TRY(hipEventRecord(w.events[ev++], stream));
+                    if (stats)
+                        hipLaunchKernelGGL((k_wf_mesh<R, true>), dim3(isect_blocks), dim3(256), lds, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc);
+                    else
+                        hipLaunchKernelGGL((k_wf_mesh<R, false>), dim3(isect_blocks), dim3(256), lds, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc);
+                    HIP_TRY(hipEventRecord(w.events[ev++], stream));
+                } else {
+                    HIP_TRY(hipEventRecord(w.events[ev++], stream));
+                    if (stats)
+                        hipLaunchKernelGGL((k_wf_intersect<R, true>), dim3(isect_blocks), dim3(256), lds, stream, ds.view, pool, w.queue[qi], w.d_ctr, s->d_counters, refill_min);
+                    else
+                        hipLaunchKernelGGL((k_wf_intersect<R, false>), dim3(isect_blocks), dim3(256), lds, stream, ds.view, pool, w.queue[qi], w.d_ctr, s->d_counters, refill_min);
+                    HIP_TRY(hipEventRecord(w.events[ev++], stream));
+                }
                 if (stats)
                     hipLaunchKernelGGL((k_wf_shade<R, true>), dim3((upper + 255) / 256), dim3(256), 0, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters);
                 else
@@ -666,6 +698,7 @@ void rt_scene_destroy(RtScene* s) {
     for (void* p : s->wf.allocs) (void)hipFree(p);
     if (s->wf.queue[0]) (void)hipFree(s->wf.queue[0]);
     if (s->wf.queue[1]) (void)hipFree(s->wf.queue[1]);
+    if (s->wf.mesh_queue) (void)hipFree(s->wf.mesh_queue);
     if (s->wf.d_ctr) (void)hipFree(s->wf.d_ctr);
     if (s->wf.h_ctr) (void)hipHostFree(s->wf.h_ctr);
     if (s->wf.sample_L) (void)hipFree(s->wf.sample_L);

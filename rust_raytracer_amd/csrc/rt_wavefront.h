@@ -20,6 +20,15 @@
 #pragma once
 #include "rt_device.h"
 
+// Minimum waves per SIMD requested from the register allocator (second __launch_bounds__
+// argument); tuned on MI355X, see DESIGN.md.
+#ifndef RT_ISECT_WAVES
+#define RT_ISECT_WAVES 3
+#endif
+// NOTE: k_wf_shade deliberately has NO waves-per-SIMD hint: with `__launch_bounds__(256, 3)` hipcc
+// (ROCm 7.2) produced different Dielectric results (caught by the bit-exact parity tests) and the
+// hint bought no speed (3 -> 4 waves/SIMD: +1 %).
+
 namespace rt {
 
 template <typename R>
@@ -38,8 +47,8 @@ struct WfPool {
 struct WfCounters {
     uint32_t n_in;        // entries of the current queue
     uint32_t n_out;       // entries appended to the next queue
-    uint32_t cursor;      // next queue entry to hand out (intersect kernel)
-    uint32_t _pad;
+    uint32_t cursor;      // next queue entry to hand out (persistent intersect / mesh kernel)
+    uint32_t n_mesh;      // entries of the mesh queue (paths whose ray enters the deferred mesh's box)
     unsigned long long next_sample;  // next sample (within the group) to start
 };
 
@@ -98,7 +107,7 @@ RT_DEV uint32_t lane_prefix(unsigned long long mask) {
 // machine (scene program counter + BVH traversal state), idle lanes are refilled from the queue.
 // ---------------------------------------------------------------------------------------------
 template <typename R, bool STATS>
-__global__ void __launch_bounds__(256) k_wf_intersect(SceneView<R> sc, WfPool<R> pool, const uint32_t* __restrict__ queue,
+__global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<R> sc, WfPool<R> pool, const uint32_t* __restrict__ queue,
                                                       WfCounters* __restrict__ ctr, DeviceCounters* counters, uint32_t refill_min) {
     extern __shared__ int lds_stack[];
     int* stack = lds_stack + threadIdx.x;
@@ -297,6 +306,283 @@ __global__ void __launch_bounds__(256) k_wf_intersect(SceneView<R> sc, WfPool<R>
 }
 
 // ---------------------------------------------------------------------------------------------
+// Split intersect for scenes with ONE mesh instance (all BASELINE configs):
+//   k_wf_prims  every lane runs the same scene program over spheres / quads / sky / sun (uniform
+//               control flow); the mesh op is deferred: paths whose object-space ray enters the
+//               mesh's root box with the interval left by the other primitives are appended
+//               (ballot + prefix sum) to the mesh queue.
+//   k_wf_mesh   persistent waves that do nothing but BVH traversal, "while-while": all lanes
+//               descend inner nodes until each holds a leaf, then all test triangles; idle lanes
+//               are refilled from the mesh queue.
+// Closest-hit semantics are those of the in-order program: the nearest t wins and, at exactly equal
+// t, the op that comes first in the reference's visiting order (its tests use strict `t < closest`).
+// ---------------------------------------------------------------------------------------------
+template <typename R, bool STATS>
+__global__ void __launch_bounds__(256) k_wf_prims(SceneView<R> sc, WfPool<R> pool, const uint32_t* __restrict__ queue,
+                                                  uint32_t* __restrict__ mesh_queue, WfCounters* __restrict__ ctr,
+                                                  DeviceCounters* counters, int32_t mesh_pc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = ctr->n_in;
+    const uint32_t lane = threadIdx.x & 63u;
+    const R t_lo = R(0.001);
+    bool active = i < n;
+    bool to_mesh = false;
+    uint32_t slot = 0;
+    LaneCounters cnt;
+    if (active) {
+        slot = queue[i];
+        const Ray<R> wray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
+        Ray<R> cur = wray;
+        Ray<R> mesh_ray = wray;
+        Best<R> best;
+        best.t = Lim<R>::inf(); best.pc = -1; best.tri = -1; best.u = R(0); best.v = R(0);
+        bool mesh_reached = false;
+        int32_t pc = 0;
+        if (STATS) cnt.rays++;
+        for (;;) {
+            const Op op = sc.ops[pc];
+            if (op.type == OP_END) break;
+            switch (op.type) {
+                case OP_BOUNDS:
+                    if (!test_bounding_box(sc.bounds[op.arg], cur, t_lo, best.t)) {
+                        pc = op.skip;
+                        continue;
+                    }
+                    break;
+                case OP_XFORM_PUSH: {
+                    const Xform<R>& x = sc.xforms[op.arg];
+                    cur = make_ray(xform_apply(x.inv, cur.o, R(1)), xform_apply(x.inv, cur.d, R(0)));
+                    break;
+                }
+                case OP_XFORM_POP:
+                    cur = ray_in_chain(sc, wray, op.chain);
+                    break;
+                case OP_SPHERE: {
+                    R t;
+                    if (STATS) cnt.prim_tests++;
+                    if (sphere_test(sc.spheres[op.arg], cur, t_lo, best.t, t)) { best.t = t; best.pc = pc; }
+                    break;
+                }
+                case OP_PLANE: {
+                    R t, u, v;
+                    if (STATS) cnt.prim_tests++;
+                    if (plane_test(sc.planes[op.arg], cur, t_lo, best.t, t, u, v)) { best.t = t; best.pc = pc; best.u = u; best.v = v; }
+                    break;
+                }
+                case OP_MESH:  // deferred (pc == mesh_pc: the only mesh op of this program)
+                    mesh_reached = true;
+                    mesh_ray = cur;
+                    break;
+                case OP_SKY:
+                    if (STATS) cnt.prim_tests++;
+                    if (!(Lim<R>::inf() > best.t)) { best.t = Lim<R>::inf(); best.pc = pc; }
+                    break;
+                case OP_SUN: {
+                    if (STATS) cnt.prim_tests++;
+                    const SunPrim<R>& s = sc.suns[op.arg];
+                    V3<R> unit_dir = to_unit(cur.d);
+                    if (!(fabs(dot(ld3(s.direction), unit_dir) - R(1)) > R(0.001)) && !(Lim<R>::max() >= best.t)) {
+                        best.t = Lim<R>::max();
+                        best.pc = pc;
+                    }
+                    break;
+                }
+                default: break;
+            }
+            pc++;
+        }
+        pool.ht[slot] = best.t; pool.hu[slot] = best.u; pool.hv[slot] = best.v;
+        pool.hpc[slot] = best.pc; pool.htri[slot] = best.tri;
+        if (mesh_reached) {
+            // does the ray enter the mesh's root box inside (t_lo, best.t]?  (culling only: conservative)
+            const MeshInst& mi = sc.meshes[sc.ops[mesh_pc].arg];
+            const BvhNode<R>& root = sc.nodes[mi.node_base];
+            const R big = sizeof(R) == 8 ? R(1e150) : R(1e18);
+            V3<R> inv = {fabs(mesh_ray.inv.x) > big ? copysign(big, mesh_ray.inv.x) : mesh_ray.inv.x,
+                         fabs(mesh_ray.inv.y) > big ? copysign(big, mesh_ray.inv.y) : mesh_ray.inv.y,
+                         fabs(mesh_ray.inv.z) > big ? copysign(big, mesh_ray.inv.z) : mesh_ray.inv.z};
+            V3<R> oi = mesh_ray.o * inv;
+            R lo[3], hi[3];
+            for (int a = 0; a < 3; a++) {  // union of the two child boxes of the root
+                lo[a] = fmin(root.lo0[a], root.c1 == kEmptyChild ? root.lo0[a] : root.lo1[a]);
+                hi[a] = fmax(root.hi0[a], root.c1 == kEmptyChild ? root.hi0[a] : root.hi1[a]);
+            }
+            R t0x = lo[0] * inv.x - oi.x, t1x = hi[0] * inv.x - oi.x;
+            R t0y = lo[1] * inv.y - oi.y, t1y = hi[1] * inv.y - oi.y;
+            R t0z = lo[2] * inv.z - oi.z, t1z = hi[2] * inv.z - oi.z;
+            R tn = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmax(fmin(t0z, t1z), t_lo));
+            R tf = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmin(fmax(t0z, t1z), best.t));
+            to_mesh = (tn <= tf) && root.c0 != kEmptyChild;
+        }
+    }
+    unsigned long long m = __ballot(to_mesh);
+    if (m) {
+        uint32_t cntm = uint32_t(__popcll(m));
+        uint32_t base = 0;
+        int leader = __ffsll((long long)m) - 1;
+        if (int(lane) == leader) base = atomicAdd(&ctr->n_mesh, cntm);
+        base = __shfl(base, leader);
+        if (to_mesh) mesh_queue[base + lane_prefix(m)] = slot;
+    }
+    if (STATS) {
+        unsigned long long r = __ballot(active);
+        // one atomic per wave and counter
+        uint32_t rays = cnt.rays, prims = cnt.prim_tests;
+        for (int off = 32; off > 0; off >>= 1) { rays += __shfl_down(rays, off); prims += __shfl_down(prims, off); }
+        if (lane == 0 && r) {
+            atomicAdd(&counters->rays, (unsigned long long)rays);
+            atomicAdd(&counters->prim_tests, (unsigned long long)prims);
+        }
+    }
+}
+
+template <typename R, bool STATS>
+__global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc, WfPool<R> pool, const uint32_t* __restrict__ mesh_queue,
+                                                                 WfCounters* __restrict__ ctr, DeviceCounters* counters,
+                                                                 uint32_t refill_min, uint32_t inner_min, int32_t mesh_pc) {
+    extern __shared__ int lds_stack[];
+    int* stack = lds_stack + threadIdx.x;
+    const int stride = int(blockDim.x);
+    const uint32_t n = ctr->n_mesh;
+    const uint32_t lane = threadIdx.x & 63u;
+    const R t_lo = R(0.001);
+    const Op mop = sc.ops[mesh_pc];
+    const MeshInst mi = sc.meshes[mop.arg];
+    const BvhNode<R>* nodes = sc.nodes + mi.node_base;
+    const TriRec<R>* tris = sc.tris + mi.tri_base;
+    const bool hit_back = (mi.flags & RT_MESH_HIT_BACK_FACES) != 0;
+    const R big = sizeof(R) == 8 ? R(1e150) : R(1e18);
+
+    LaneCounters cnt;
+    bool has = false;
+    bool exhausted = false;
+    bool found = false;      // a triangle closer than the other primitives' hit was found
+    uint32_t slot = 0;
+    V3<R> o{}, d{}, inv{}, oi{};
+    R t_max = R(0), hit_u = R(0), hit_v = R(0);
+    int32_t hit_tri = -1;
+    int32_t node = 0;        // >= 0 inner node, < 0 leaf
+    int sp = 0;
+
+    for (;;) {
+        // ---- refill ----
+        unsigned long long idle = __ballot(!has);
+        uint32_t n_idle = uint32_t(__popcll(idle));
+        if (!exhausted && n_idle >= refill_min) {
+            uint32_t base = 0;
+            int leader = __ffsll((long long)idle) - 1;
+            if (int(lane) == leader) base = atomicAdd(&ctr->cursor, n_idle);
+            base = __shfl(base, leader);
+            if (base + n_idle >= n) exhausted = true;
+            uint32_t my = base + lane_prefix(idle);
+            if (!has && my < n) {
+                slot = mesh_queue[my];
+                Ray<R> wray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
+                Ray<R> ray = ray_in_chain(sc, wray, mop.chain);
+                o = ray.o;
+                d = ray.d;
+                inv = {fabs(ray.inv.x) > big ? copysign(big, ray.inv.x) : ray.inv.x,
+                       fabs(ray.inv.y) > big ? copysign(big, ray.inv.y) : ray.inv.y,
+                       fabs(ray.inv.z) > big ? copysign(big, ray.inv.z) : ray.inv.z};
+                oi = o * inv;
+                // The other primitives' closest hit bounds the search.  At exactly equal t the op that
+                // comes first in program order wins: if that is the mesh, t == bound must be accepted.
+                R bound = pool.ht[slot];
+                int32_t bpc = pool.hpc[slot];
+                t_max = (bpc > mesh_pc && bound < Lim<R>::inf()) ? nextafter(bound, Lim<R>::inf()) : bound;
+                found = false;
+                hit_tri = -1;
+                node = 0;
+                sp = 0;
+                has = true;
+                if (STATS) cnt.mesh_rays++;
+            }
+        }
+        if (__ballot(has) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- inner nodes: descend until (nearly) every lane holds a leaf or has finished ----
+        for (;;) {
+            unsigned long long inner = __ballot(has && node >= 0);
+            if (inner == 0ull) break;
+            // a few stragglers do not keep a wave full of ready leaves waiting
+            if (uint32_t(__popcll(inner)) < inner_min && __ballot(has && node < 0) != 0ull) break;
+            if (has && node >= 0) {
+                const BvhNode<R>& nd = nodes[node];
+                if (STATS) cnt.node_visits++;
+                R t0x = nd.lo0[0] * inv.x - oi.x, t1x = nd.hi0[0] * inv.x - oi.x;
+                R t0y = nd.lo0[1] * inv.y - oi.y, t1y = nd.hi0[1] * inv.y - oi.y;
+                R t0z = nd.lo0[2] * inv.z - oi.z, t1z = nd.hi0[2] * inv.z - oi.z;
+                R near0 = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmax(fmin(t0z, t1z), t_lo));
+                R far0 = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmin(fmax(t0z, t1z), t_max));
+                R s0x = nd.lo1[0] * inv.x - oi.x, s1x = nd.hi1[0] * inv.x - oi.x;
+                R s0y = nd.lo1[1] * inv.y - oi.y, s1y = nd.hi1[1] * inv.y - oi.y;
+                R s0z = nd.lo1[2] * inv.z - oi.z, s1z = nd.hi1[2] * inv.z - oi.z;
+                R near1 = fmax(fmax(fmin(s0x, s1x), fmin(s0y, s1y)), fmax(fmin(s0z, s1z), t_lo));
+                R far1 = fmin(fmin(fmax(s0x, s1x), fmax(s0y, s1y)), fmin(fmax(s0z, s1z), t_max));
+                int32_t c0 = nd.c0, c1 = nd.c1;
+                bool h0 = (near0 <= far0) && c0 != kEmptyChild;
+                bool h1 = (near1 <= far1) && c1 != kEmptyChild;
+                if (h0 && h1) {
+                    bool first0 = near0 <= near1;
+                    stack[sp * stride] = first0 ? c1 : c0;
+                    sp++;
+                    node = first0 ? c0 : c1;
+                } else if (h0) node = c0;
+                else if (h1) node = c1;
+                else if (sp > 0) { sp--; node = stack[sp * stride]; }
+                else { has = false; }  // traversal finished (result written below)
+                if (!has) {
+                    if (found) {
+                        pool.ht[slot] = t_max; pool.hu[slot] = hit_u; pool.hv[slot] = hit_v;
+                        pool.hpc[slot] = mesh_pc; pool.htri[slot] = hit_tri;
+                    }
+                }
+            }
+        }
+        // ---- leaves: every lane that holds one tests its triangles, then pops ----
+        if (has && node < 0) {
+            uint32_t code = uint32_t(~node);
+            uint32_t first = code >> 3, count = (code & 7u) + 1u;
+            for (uint32_t k = 0; k < count; k++) {
+                const TriRec<R>& tr = tris[first + k];
+                if (STATS) cnt.tri_tests++;
+                V3<R> edge1 = ld3(tr.e1), edge2 = ld3(tr.e2);
+                V3<R> ray_x_edge2 = cross(d, edge2);
+                R det = dot(edge1, ray_x_edge2);
+                R dd = hit_back ? fabs(det) : det;
+                if (dd < Lim<R>::eps()) continue;
+                R inv_det = R(1) / det;
+                V3<R> b = o - ld3(tr.v0);
+                R u = dot(b, ray_x_edge2) * inv_det;
+                if (u < R(0) || u > R(1)) continue;
+                V3<R> b_x_edge1 = cross(b, edge1);
+                R v = dot(d, b_x_edge1) * inv_det;
+                if (v < R(0) || u + v > R(1)) continue;
+                R t = dot(edge2, b_x_edge1) * inv_det;
+                if (t <= t_lo || t_max <= t) continue;
+                t_max = t; hit_u = u; hit_v = v; hit_tri = int32_t(mi.tri_base + first + k);
+                found = true;
+            }
+            if (sp > 0) { sp--; node = stack[sp * stride]; }
+            else {
+                has = false;
+                if (found) {
+                    pool.ht[slot] = t_max; pool.hu[slot] = hit_u; pool.hv[slot] = hit_v;
+                    pool.hpc[slot] = mesh_pc; pool.htri[slot] = hit_tri;
+                }
+            }
+        }
+    }
+    if (STATS) {
+        atomicAdd(&counters->mesh_rays, (unsigned long long)cnt.mesh_rays);
+        atomicAdd(&counters->node_visits, (unsigned long long)cnt.node_visits);
+        atomicAdd(&counters->tri_tests, (unsigned long long)cnt.tri_tests);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Shade: one path vertex per lane (camera.rs:295-331), regeneration and queue compaction.
 // ---------------------------------------------------------------------------------------------
 template <typename R, bool STATS>
@@ -376,6 +662,7 @@ __global__ void k_wf_advance(WfCounters* ctr) {
     ctr->n_in = ctr->n_out;
     ctr->n_out = 0;
     ctr->cursor = 0;
+    ctr->n_mesh = 0;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -35,6 +35,7 @@ SCENES = {
     "single_light": ["tests/scenes/single_light", "-w=37", "-s=9", "--seed=8"],     # width not a tile multiple
     "test": ["scenes/test", "-w=45", "-s=16", "--seed=9"],
     "tonemap_test": ["scenes/tonemap_test", "-w=40", "-s=16", "--seed=10"],
+    "two_meshes": ["tests/scenes/two_meshes", "-w=48", "-s=16", "--seed=11"],   # >1 mesh op: combined intersect kernel
 }
 
 
@@ -128,7 +129,10 @@ def test_stats_counters_and_collect_flag(dev):
     q.pipeline = api.RT_PIPELINE_MEGAKERNEL
     scene.render(hs.camera, q)
     sm = scene.stats()
-    assert (sm.rays, sm.node_visits, sm.tri_tests, sm.prim_tests) == (st.rays, st.node_visits, st.tri_tests, st.prim_tests)
+    # same rays; the split wavefront intersect tests the other primitives first, so the mesh
+    # traversal starts with a tighter interval: never more BVH work than the in-order megakernel
+    assert sm.rays == st.rays
+    assert st.node_visits <= sm.node_visits and st.tri_tests <= sm.tri_tests
     p.collect_stats = 0
     np.testing.assert_array_equal(scene.render(hs.camera, p), with_stats)   # counting never changes pixels
     _, ost = pyoracle.render(hs.desc, hs.camera, hs.params)

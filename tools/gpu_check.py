@@ -42,7 +42,7 @@ def compare(args, label):
 
 if __name__ == "__main__":
     print("devices", api.load_device_lib().rt_device_count())
-    for sc in sys.argv[1:] or ["sun_sky", "bvh_spheres", "hollow_glass", "nested_transform", "single_light", "sky_only"]:
+    for sc in sys.argv[1:] or ["sun_sky", "bvh_spheres", "hollow_glass", "nested_transform", "single_light", "sky_only", "two_meshes"]:
         compare(["tests/scenes/" + sc, "-s=16", "--seed=2"], sc)
     compare(["-w=96", "-s=16", "--seed=7"], "default")
     compare(["scenes/light_test", "-w=96", "-s=32", "-t=2", "--seed=3"], "light_test")
