@@ -17,6 +17,10 @@
 namespace rt {
 
 #define RT_DEV __device__ __forceinline__
+// Notes from tuning: (1) a single `__noinline__` helper (to_unit) raised the shade kernel
+// from 129 to 217 VGPRs through the call ABI; (2) restructuring shade() so that every heavy routine has one
+// call site halved its code (71 KB -> 36 KB) but also raised it to 211 VGPRs and bought no time.  Everything
+// is therefore inlined and shade() keeps the reference's per-material structure.
 
 template <typename R> struct Lim;
 template <> struct Lim<double> {
@@ -397,6 +401,33 @@ RT_DEV void world_test(const SceneView<R>& sc, const Ray<R>& wray, R t_lo, Best<
         }
         pc++;
     }
+}
+
+// ------------------------------------------------------------------ small tables in LDS
+// Copies the packed small tables into LDS (whole workgroup, 16 B per lane per trip) and returns a
+// view whose table pointers point into LDS.  Must be called by every thread of the block.
+template <typename R>
+RT_DEV SceneView<R> scene_tables_to_lds(const SceneView<R>& g, char* lds) {
+    const uint32_t n16 = (g.lay.total_bytes + 15u) / 16u;
+    const uint4* src = reinterpret_cast<const uint4*>(g.small_blob);
+    uint4* dst = reinterpret_cast<uint4*>(lds);
+    for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    SceneView<R> v = g;
+    v.ops = reinterpret_cast<const Op*>(lds + g.lay.ops);
+    v.bounds = reinterpret_cast<const Bounds<R>*>(lds + g.lay.bounds);
+    v.chain_offsets = reinterpret_cast<const int32_t*>(lds + g.lay.chain_offsets);
+    v.chain_items = reinterpret_cast<const int32_t*>(lds + g.lay.chain_items);
+    v.xforms = reinterpret_cast<const Xform<R>*>(lds + g.lay.xforms);
+    v.spheres = reinterpret_cast<const SpherePrim<R>*>(lds + g.lay.spheres);
+    v.planes = reinterpret_cast<const PlanePrim<R>*>(lds + g.lay.planes);
+    v.suns = reinterpret_cast<const SunPrim<R>*>(lds + g.lay.suns);
+    v.meshes = reinterpret_cast<const MeshInst*>(lds + g.lay.meshes);
+    v.materials = reinterpret_cast<const MaterialRec*>(lds + g.lay.materials);
+    v.material_params = reinterpret_cast<const MaterialParams<R>*>(lds + g.lay.material_params);
+    v.textures = reinterpret_cast<const TextureRec<R>*>(lds + g.lay.textures);
+    v.lights = reinterpret_cast<const LightRec*>(lds + g.lay.lights);
+    return v;
 }
 
 // ------------------------------------------------------------------ HitRecord (object.rs:32-72)

@@ -308,10 +308,40 @@ struct DeviceScene {
         if ((st = buf.upload(mparams, &view.material_params)) != RT_OK) return st;
         if ((st = buf.upload(textures, &view.textures)) != RT_OK) return st;
         if ((st = buf.upload(cs.lights, &view.lights)) != RT_OK) return st;
+        // the same small tables once more, packed for LDS staging
+        {
+            std::vector<char> blob;
+            auto put = [&](const void* data, size_t bytes) -> uint32_t {
+                size_t off = (blob.size() + 15) & ~size_t(15);
+                blob.resize(off + bytes);
+                if (bytes) std::memcpy(blob.data() + off, data, bytes);
+                return uint32_t(off);
+            };
+            SmallLayout& L = view.lay;
+            L.ops = put(cs.ops.data(), cs.ops.size() * sizeof(Op));
+            L.bounds = put(bounds.data(), bounds.size() * sizeof(Bounds<R>));
+            L.chain_offsets = put(cs.chain_offsets.data(), cs.chain_offsets.size() * 4);
+            L.chain_items = put(cs.chain_items.data(), cs.chain_items.size() * 4);
+            L.xforms = put(xforms.data(), xforms.size() * sizeof(Xform<R>));
+            L.spheres = put(spheres.data(), spheres.size() * sizeof(SpherePrim<R>));
+            L.planes = put(planes.data(), planes.size() * sizeof(PlanePrim<R>));
+            L.suns = put(suns.data(), suns.size() * sizeof(SunPrim<R>));
+            L.meshes = put(cs.meshes.data(), cs.meshes.size() * sizeof(MeshInst));
+            L.materials = put(cs.materials.data(), cs.materials.size() * sizeof(MaterialRec));
+            L.material_params = put(mparams.data(), mparams.size() * sizeof(MaterialParams<R>));
+            L.textures = put(textures.data(), textures.size() * sizeof(TextureRec<R>));
+            L.lights = put(cs.lights.data(), cs.lights.size() * sizeof(LightRec));
+            blob.resize((blob.size() + 15) & ~size_t(15));
+            L.total_bytes = uint32_t(blob.size());
+            if ((st = buf.upload(blob, &view.small_blob)) != RT_OK) return st;
+        }
         view.n_lights = int32_t(cs.lights.size());
         view.lights_is_list = cs.lights_is_list;
         view.stack_entries = int32_t(cs.max_bvh_depth) + 2;
         view.n_ops = int32_t(cs.ops.size());
+        // The uploads above went through the null stream (small pageable copies may return once
+        // staged); the render kernels run on a NON-BLOCKING stream that is not ordered against it.
+        HIP_TRY(hipDeviceSynchronize());
         return RT_OK;
     }
 };
@@ -542,6 +572,9 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     const uint32_t isect_blocks = uint32_t(n_cu) * uint32_t(blocks_per_cu);
     const uint32_t refill_min = env_u32("RT_WF_REFILL", 32);  // measured optimum (64 = no refill: -20 %)
     const uint32_t inner_min = env_u32("RT_WF_INNER_MIN", 16);
+    // small tables staged in LDS by the prims / shade kernels when they fit
+    const bool lds_tables = ds.view.lay.total_bytes <= 48u * 1024u && env_u32("RT_LDS_TABLES", 1) != 0;
+    const size_t lds_small = lds_tables ? size_t(ds.view.lay.total_bytes) : 0;
     const uint32_t check_every = env_u32("RT_WF_CHECK", 8);
 
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), stream));
@@ -571,10 +604,10 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
             size_t ev = 0;
             for (uint32_t k = 0; k < check_every; k++) {
                 if (split) {
-                    if (stats)
-                        hipLaunchKernelGGL((k_wf_prims<R, true>), dim3((upper + 255) / 256), dim3(256), 0, stream, ds.view, pool, w.queue[qi], w.mesh_queue, w.d_ctr, s->d_counters, mesh_pc);
-                    else
-                        hipLaunchKernelGGL((k_wf_prims<R, false>), dim3((upper + 255) / 256), dim3(256), 0, stream, ds.view, pool, w.queue[qi], w.mesh_queue, w.d_ctr, s->d_counters, mesh_pc);
+#define RT_LAUNCH_PRIMS(ST, L) hipLaunchKernelGGL((k_wf_prims<R, ST, L>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), lds_small + (WF_CHUNK + 4) * 4, stream, ds.view, pool, w.queue[qi], w.mesh_queue, w.d_ctr, s->d_counters, mesh_pc)
+                    if (stats) { if (lds_tables) RT_LAUNCH_PRIMS(true, true); else RT_LAUNCH_PRIMS(true, false); }
+                    else { if (lds_tables) RT_LAUNCH_PRIMS(false, true); else RT_LAUNCH_PRIMS(false, false); }
+#undef RT_LAUNCH_PRIMS
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
                     if (stats)
                         hipLaunchKernelGGL((k_wf_mesh<R, true>), dim3(isect_blocks), dim3(256), lds, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc);
@@ -589,10 +622,10 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
                         hipLaunchKernelGGL((k_wf_intersect<R, false>), dim3(isect_blocks), dim3(256), lds, stream, ds.view, pool, w.queue[qi], w.d_ctr, s->d_counters, refill_min);
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 }
-                if (stats)
-                    hipLaunchKernelGGL((k_wf_shade<R, true>), dim3((upper + 255) / 256), dim3(256), 0, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters);
-                else
-                    hipLaunchKernelGGL((k_wf_shade<R, false>), dim3((upper + 255) / 256), dim3(256), 0, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters);
+#define RT_LAUNCH_SHADE(ST, L) hipLaunchKernelGGL((k_wf_shade<R, ST, L>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), lds_small + (2 * WF_CHUNK + 8) * 4, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters)
+                if (stats) { if (lds_tables) RT_LAUNCH_SHADE(true, true); else RT_LAUNCH_SHADE(true, false); }
+                else { if (lds_tables) RT_LAUNCH_SHADE(false, true); else RT_LAUNCH_SHADE(false, false); }
+#undef RT_LAUNCH_SHADE
                 hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(1), 0, stream, w.d_ctr);
                 qi ^= 1;
                 isect_launches++;

@@ -128,6 +128,15 @@ struct LightRec {
     int32_t index;  // into planes / spheres / suns
 };
 
+// All the small tables (everything except BVH nodes, triangle records and attributes) are ALSO
+// uploaded as one contiguous blob, so that a workgroup can stage them in LDS with one cooperative
+// copy and walk the scene program / materials / lights without global-memory round trips.
+struct SmallLayout {
+    uint32_t ops, bounds, chain_offsets, chain_items, xforms, spheres, planes, suns, meshes, materials,
+        material_params, textures, lights;  // byte offsets, 16-B aligned
+    uint32_t total_bytes;
+};
+
 // Device pointers.  Passed to kernels by value.
 template <typename R>
 struct SceneView {
@@ -151,6 +160,8 @@ struct SceneView {
     int32_t lights_is_list;  // lights root is an ObjectList (list.rs:80-100) vs a single object
     int32_t stack_entries;   // per-lane LDS traversal stack size
     int32_t n_ops;
+    const char* small_blob;  // the tables above packed per SmallLayout (global memory)
+    SmallLayout lay;
 };
 
 template <typename R>

@@ -102,6 +102,55 @@ RT_DEV uint32_t lane_prefix(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
 }
 
+// A single global word sustains only ~90 atomics/us on MI355X (MI355X_MICROARCH.md, "dequeue"), so
+// one atomic per WAVE on a queue tail (16 M paths = 260 k waves = 3 ms per launch) was the
+// bottleneck of every kernel here.  Queue traffic is therefore aggregated per WORKGROUP through
+// LDS lists (chunked kernels: one global atomic per WF_CHUNK entries) and the persistent kernels
+// reserve WF_BATCH entries per atomic.
+constexpr uint32_t WF_CHUNK = 4096;  // queue entries handled by one workgroup of the chunked kernels
+constexpr uint32_t WF_BATCH = 256;   // queue entries a wave of a persistent kernel reserves at once
+
+// Appends `value` of the lanes with `pred` to an LDS list: ballot + mbcnt prefix, one LDS atomic per wave.
+RT_DEV void lds_append(bool pred, uint32_t value, uint32_t* list, uint32_t* count) {
+    unsigned long long m = __ballot(pred);
+    if (m) {
+        int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (int(threadIdx.x & 63u) == leader) base = atomicAdd(count, uint32_t(__popcll(m)));
+        base = __shfl(base, leader);
+        if (pred) list[base + lane_prefix(m)] = value;
+    }
+}
+
+// Wave-level queue reader of the persistent kernels: hands out entries [cur, end) of a reserved batch.
+struct WaveRange {
+    uint32_t cur = 0, end = 0;
+};
+// Gives every idle lane (bit set in `idle`) a queue index if one is available; returns true in
+// `take` lanes.  Sets `exhausted` when the queue has been handed out completely.
+RT_DEV bool wave_fetch(WaveRange& r, unsigned long long idle, uint32_t* cursor, uint32_t n, bool& exhausted, uint32_t& my) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (r.cur >= r.end) {
+        uint32_t base = 0;
+        int leader = __ffsll((long long)idle) - 1;
+        if (int(lane) == leader) base = atomicAdd(cursor, WF_BATCH);
+        base = __shfl(base, leader);
+        if (base >= n) {
+            exhausted = true;
+            return false;
+        }
+        r.cur = base;
+        r.end = min(base + WF_BATCH, n);
+    }
+    uint32_t avail = r.end - r.cur;
+    uint32_t rank = lane_prefix(idle);
+    bool take = ((idle >> lane) & 1ull) && rank < avail;
+    my = r.cur + rank;
+    uint32_t n_idle = uint32_t(__popcll(idle));
+    r.cur += n_idle < avail ? n_idle : avail;
+    return take;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Intersect: world.test for every queued path.  Persistent waves; each lane is a small state
 // machine (scene program counter + BVH traversal state), idle lanes are refilled from the queue.
@@ -113,13 +162,13 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<
     int* stack = lds_stack + threadIdx.x;
     const int stride = int(blockDim.x);
     const uint32_t n = ctr->n_in;
-    const uint32_t lane = threadIdx.x & 63u;
     const R t_lo = R(0.001);
 
     LaneCounters cnt;
     bool has = false;        // this lane holds a ray
     bool in_mesh = false;    // ... and is inside a mesh BVH
     bool exhausted = false;  // wave-uniform: the queue has been handed out completely
+    WaveRange range;
     uint32_t slot = 0;
     Ray<R> wray{}, cur{};
     Best<R> best{};
@@ -138,13 +187,8 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<
         unsigned long long idle = __ballot(!has);
         uint32_t n_idle = uint32_t(__popcll(idle));
         if (!exhausted && n_idle >= refill_min) {
-            uint32_t base = 0;
-            int leader = __ffsll((long long)idle) - 1;
-            if (int(lane) == leader) base = atomicAdd(&ctr->cursor, n_idle);
-            base = __shfl(base, leader);
-            if (base + n_idle >= n) exhausted = true;
-            uint32_t my = base + lane_prefix(idle);
-            if (!has && my < n) {
+            uint32_t my = 0;
+            if (wave_fetch(range, idle, &ctr->cursor, n, exhausted, my)) {
                 slot = queue[my];
                 wray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
                 cur = wray;
@@ -317,18 +361,28 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<
 // Closest-hit semantics are those of the in-order program: the nearest t wins and, at exactly equal
 // t, the op that comes first in the reference's visiting order (its tests use strict `t < closest`).
 // ---------------------------------------------------------------------------------------------
-template <typename R, bool STATS>
-__global__ void __launch_bounds__(256) k_wf_prims(SceneView<R> sc, WfPool<R> pool, const uint32_t* __restrict__ queue,
+template <typename R, bool STATS, bool LDS>
+__global__ void __launch_bounds__(256) k_wf_prims(SceneView<R> sc_g, WfPool<R> pool, const uint32_t* __restrict__ queue,
                                                   uint32_t* __restrict__ mesh_queue, WfCounters* __restrict__ ctr,
                                                   DeviceCounters* counters, int32_t mesh_pc) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ __align__(16) char lds_raw[];
+    uint32_t* mesh_list = reinterpret_cast<uint32_t*>(lds_raw);  // [WF_CHUNK]
+    uint32_t* lc = mesh_list + WF_CHUNK;                        // [0] list length, [1] queue base
+    char* tables = reinterpret_cast<char*>(lc + 4);
+    if (threadIdx.x < 4) lc[threadIdx.x] = 0;
+    SceneView<R> sc = sc_g;
+    if constexpr (LDS) sc = scene_tables_to_lds(sc_g, tables);
+    else __syncthreads();
     const uint32_t n = ctr->n_in;
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t begin = blockIdx.x * WF_CHUNK;
+    const uint32_t end = min(n, begin + WF_CHUNK);
     const R t_lo = R(0.001);
-    bool active = i < n;
+    LaneCounters cnt;
+    for (uint32_t base = begin; base < end; base += blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    bool active = i < end;
     bool to_mesh = false;
     uint32_t slot = 0;
-    LaneCounters cnt;
     if (active) {
         slot = queue[i];
         const Ray<R> wray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
@@ -415,21 +469,18 @@ __global__ void __launch_bounds__(256) k_wf_prims(SceneView<R> sc, WfPool<R> poo
             to_mesh = (tn <= tf) && root.c0 != kEmptyChild;
         }
     }
-    unsigned long long m = __ballot(to_mesh);
-    if (m) {
-        uint32_t cntm = uint32_t(__popcll(m));
-        uint32_t base = 0;
-        int leader = __ffsll((long long)m) - 1;
-        if (int(lane) == leader) base = atomicAdd(&ctr->n_mesh, cntm);
-        base = __shfl(base, leader);
-        if (to_mesh) mesh_queue[base + lane_prefix(m)] = slot;
+    lds_append(to_mesh, slot, mesh_list, &lc[0]);
     }
+    __syncthreads();
+    const uint32_t n_list = lc[0];
+    if (threadIdx.x == 0 && n_list) lc[1] = atomicAdd(&ctr->n_mesh, n_list);  // ONE global atomic per workgroup
+    __syncthreads();
+    const uint32_t qb = lc[1];
+    for (uint32_t j = threadIdx.x; j < n_list; j += blockDim.x) mesh_queue[qb + j] = mesh_list[j];
     if (STATS) {
-        unsigned long long r = __ballot(active);
-        // one atomic per wave and counter
         uint32_t rays = cnt.rays, prims = cnt.prim_tests;
         for (int off = 32; off > 0; off >>= 1) { rays += __shfl_down(rays, off); prims += __shfl_down(prims, off); }
-        if (lane == 0 && r) {
+        if ((threadIdx.x & 63u) == 0 && rays) {
             atomicAdd(&counters->rays, (unsigned long long)rays);
             atomicAdd(&counters->prim_tests, (unsigned long long)prims);
         }
@@ -444,7 +495,6 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc
     int* stack = lds_stack + threadIdx.x;
     const int stride = int(blockDim.x);
     const uint32_t n = ctr->n_mesh;
-    const uint32_t lane = threadIdx.x & 63u;
     const R t_lo = R(0.001);
     const Op mop = sc.ops[mesh_pc];
     const MeshInst mi = sc.meshes[mop.arg];
@@ -457,6 +507,7 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc
     bool has = false;
     bool exhausted = false;
     bool found = false;      // a triangle closer than the other primitives' hit was found
+    WaveRange range;
     uint32_t slot = 0;
     V3<R> o{}, d{}, inv{}, oi{};
     R t_max = R(0), hit_u = R(0), hit_v = R(0);
@@ -469,13 +520,8 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc
         unsigned long long idle = __ballot(!has);
         uint32_t n_idle = uint32_t(__popcll(idle));
         if (!exhausted && n_idle >= refill_min) {
-            uint32_t base = 0;
-            int leader = __ffsll((long long)idle) - 1;
-            if (int(lane) == leader) base = atomicAdd(&ctr->cursor, n_idle);
-            base = __shfl(base, leader);
-            if (base + n_idle >= n) exhausted = true;
-            uint32_t my = base + lane_prefix(idle);
-            if (!has && my < n) {
+            uint32_t my = 0;
+            if (wave_fetch(range, idle, &ctr->cursor, n, exhausted, my)) {
                 slot = mesh_queue[my];
                 Ray<R> wray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
                 Ray<R> ray = ray_in_chain(sc, wray, mop.chain);
@@ -585,17 +631,29 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc
 // ---------------------------------------------------------------------------------------------
 // Shade: one path vertex per lane (camera.rs:295-331), regeneration and queue compaction.
 // ---------------------------------------------------------------------------------------------
-template <typename R, bool STATS>
-__global__ void __launch_bounds__(256) k_wf_shade(SceneView<R> sc, CameraView<R> cam, ParamsView<R> prm, WfPool<R> pool, WfGroup<R> grp,
+template <typename R, bool STATS, bool LDS>
+__global__ void __launch_bounds__(256) k_wf_shade(SceneView<R> sc_g, CameraView<R> cam, ParamsView<R> prm, WfPool<R> pool, WfGroup<R> grp,
                                                   const uint32_t* __restrict__ queue_in, uint32_t* __restrict__ queue_out,
                                                   WfCounters* __restrict__ ctr, double* __restrict__ sample_L, DeviceCounters* counters) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ __align__(16) char lds_raw[];
+    uint32_t* alive_list = reinterpret_cast<uint32_t*>(lds_raw);  // [WF_CHUNK] slots that go to the next queue
+    uint32_t* dead_list = alive_list + WF_CHUNK;                 // [WF_CHUNK] slots whose path ended
+    uint32_t* lc = dead_list + WF_CHUNK;                         // [0] n_alive [1] n_dead [2,3] sample base [4] queue base
+    char* tables = reinterpret_cast<char*>(lc + 8);
+    if (threadIdx.x < 8) lc[threadIdx.x] = 0;
+    SceneView<R> sc = sc_g;
+    if constexpr (LDS) sc = scene_tables_to_lds(sc_g, tables);
+    else __syncthreads();
     const uint32_t n = ctr->n_in;
-    const uint32_t lane = threadIdx.x & 63u;
-    bool active = i < n;
+    const uint32_t begin = blockIdx.x * WF_CHUNK;
+    const uint32_t end = min(n, begin + WF_CHUNK);
+    LaneCounters cnt;
+    // ---- phase 1: one path vertex per lane, chunk by chunk ----
+    for (uint32_t base = begin; base < end; base += blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    bool active = i < end;
     bool alive = false;
     uint32_t slot = 0;
-    LaneCounters cnt;
     if (active) {
         slot = queue_in[i];
         PathState<R> ps;
@@ -625,35 +683,45 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneView<R> sc, CameraView<R>
             sample_L[3 * s + 2] = double(ps.radiance.z);
         }
     }
-    // ---- regenerate: finished paths restart in place on the next samples ----
-    unsigned long long want = __ballot(active && !alive);
-    if (want) {
-        uint32_t n_want = uint32_t(__popcll(want));
-        unsigned long long base = 0;
-        int leader = __ffsll((long long)want) - 1;
-        if (int(lane) == leader) base = atomicAdd(&ctr->next_sample, (unsigned long long)n_want);
-        base = __shfl(base, leader);
-        if (active && !alive) {
-            unsigned long long s = base + lane_prefix(want);
-            if (s < grp.total) {
-                wf_start_sample(pool, slot, s, grp, cam, prm);
-                alive = true;
+    lds_append(active && alive, slot, alive_list, &lc[0]);
+    lds_append(active && !alive, slot, dead_list, &lc[1]);
+    }
+    __syncthreads();
+    // ---- phase 2: finished paths restart IN PLACE on the next samples (one global atomic per workgroup;
+    //      all lanes generate camera rays together: no divergence against the shading code) ----
+    const uint32_t n_dead = lc[1];
+    if (threadIdx.x == 0 && n_dead) {
+        unsigned long long b0 = atomicAdd(&ctr->next_sample, (unsigned long long)n_dead);
+        lc[2] = uint32_t(b0);
+        lc[3] = uint32_t(b0 >> 32);
+    }
+    __syncthreads();
+    const unsigned long long s_base = (unsigned long long)lc[2] | ((unsigned long long)lc[3] << 32);
+    for (uint32_t j0 = 0; j0 < n_dead; j0 += blockDim.x) {
+        const uint32_t j = j0 + threadIdx.x;
+        bool restarted = false;
+        uint32_t slot = 0;
+        if (j < n_dead) {
+            const unsigned long long s2 = s_base + j;
+            slot = dead_list[j];
+            if (s2 < grp.total) {
+                wf_start_sample(pool, slot, s2, grp, cam, prm);
+                restarted = true;
             }
         }
+        lds_append(restarted, slot, alive_list, &lc[0]);
     }
-    // ---- compact surviving slots into the next queue ----
-    unsigned long long keep = __ballot(alive);
-    if (keep) {
-        uint32_t n_keep = uint32_t(__popcll(keep));
-        uint32_t base = 0;
-        int leader = __ffsll((long long)keep) - 1;
-        if (int(lane) == leader) base = atomicAdd(&ctr->n_out, n_keep);
-        base = __shfl(base, leader);
-        if (alive) queue_out[base + lane_prefix(keep)] = slot;
-    }
+    __syncthreads();
+    // ---- phase 3: surviving slots -> next queue (one global atomic per workgroup, coalesced copy) ----
+    const uint32_t n_alive = lc[0];
+    if (threadIdx.x == 0 && n_alive) lc[4] = atomicAdd(&ctr->n_out, n_alive);
+    __syncthreads();
+    const uint32_t qb = lc[4];
+    for (uint32_t j = threadIdx.x; j < n_alive; j += blockDim.x) queue_out[qb + j] = alive_list[j];
     if (STATS) {
-        unsigned long long pt = cnt.prim_tests;
-        if (pt) atomicAdd(&counters->prim_tests, pt);
+        uint32_t prims = cnt.prim_tests;
+        for (int off = 32; off > 0; off >>= 1) prims += __shfl_down(prims, off);
+        if ((threadIdx.x & 63u) == 0 && prims) atomicAdd(&counters->prim_tests, (unsigned long long)prims);
     }
 }
 
