@@ -178,12 +178,15 @@ def main():
 
     roofline = None
     if counters is not None and counters.rays > 0 and kernel_ms:
-        # Algorithmic bytes per launch of the dominant kernel (this rank's rows):
-        #   BVH nodes fetched x node size + triangle tests x triangle record size
-        #   + one attribute record per mesh closest hit (<= mesh_rays) + framebuffer write.
-        nbytes = (counters.node_visits * counters.bytes_node + counters.tri_tests * counters.bytes_tri +
-                  counters.mesh_rays * counters.bytes_attr + counters.rays * counters.bytes_state +
-                  rows * hs.width * 32)
+        # Algorithmic bytes of the dominant kernel (this rank's rows), counted by the kernels themselves:
+        #   BVH nodes fetched x node size + triangle tests x triangle record size + path state of the
+        #   rays it handles (wavefront mesh kernel) or attribute records + frame (megakernel).
+        mega = counters.pipeline_used == api.RT_PIPELINE_MEGAKERNEL
+        nbytes = counters.node_visits * counters.bytes_node + counters.tri_tests * counters.bytes_tri
+        if mega:
+            nbytes += counters.mesh_rays * counters.bytes_attr + rows * hs.width * 32
+        else:
+            nbytes += counters.mesh_rays * counters.bytes_state
         # per LAUNCH of the dominant kernel: a step is 1 launch of the megakernel or n launches of
         # k_wf_intersect (one per wavefront iteration); durations are HIP-event times on the
         # render stream, summed by the library (RtRenderStats.traversal_kernel_ms / n_launches)
@@ -204,7 +207,11 @@ def main():
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "k_megakernel" if counters.pipeline_used == api.RT_PIPELINE_MEGAKERNEL else "k_wf_intersect",
+            "kernel": "k_megakernel" if mega else "k_wf_mesh (BVH traversal; k_wf_intersect for scenes with != 1 mesh)",
+            "note": "algorithmic bytes / kernel time; the BVH working set (~220 MB f64) is served mostly by L2 (44 % hits) "
+                    "and the 256 MB Infinity Cache, so this exceeds what HBM itself delivers; `traffic` = rocprofv3 "
+                    "FETCH_SIZE+WRITE_SIZE (fabric side, raw) of the same kernel per launch",
+            "dominant_kernel_share_of_step": (avg_ms * n_launch) / (elapsed / a.steps * 1e3),
             "kernel_ms_avg": avg_ms, "launches_per_step": n_launch, "algorithmic_bytes_per_launch": nbytes,
             "kernel_ms_per_step": avg_ms * n_launch,
             "rays_per_sample": counters.rays / max(counters.samples, 1),

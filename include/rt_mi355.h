@@ -206,7 +206,7 @@ typedef struct RtRenderStats {
     uint64_t bytes_node;          /* bytes per BVH node in the layout used                               */
     uint64_t bytes_tri;           /* bytes per triangle record                                           */
     uint64_t bytes_attr;          /* bytes of shading attributes fetched per mesh hit                    */
-    uint64_t bytes_state;         /* bytes of path state + framebuffer traffic per ray (wavefront)       */
+    uint64_t bytes_state;         /* bytes of path state the dominant kernel moves per ray it handles (0: megakernel) */
 } RtRenderStats;
 
 typedef struct RtScene RtScene;

@@ -666,8 +666,10 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     st.bytes_node = sizeof(BvhNode<R>);
     st.bytes_tri = sizeof(TriRec<R>);
     st.bytes_attr = sizeof(TriAttr<R>);
-    // path state read by intersect (ray 6R) + written (hit 3R + 8) and read+written by shade per ray
-    st.bytes_state = 6 * sizeof(R) + 3 * sizeof(R) + 8 + 4;
+    // path state moved by the DOMINANT kernel per ray it traverses: ray (6 R) + bound/op read (R + 4)
+    // + hit written when a triangle wins (3 R + 8) + queue entry (4)
+    st.bytes_state = 6 * sizeof(R) + sizeof(R) + 4 + 3 * sizeof(R) + 8 + 4;
+    if (!split) st.mesh_rays = hc.rays;  // combined kernel: every ray's state passes through it
     return RT_OK;
 }
 
