@@ -25,9 +25,9 @@
 #ifndef RT_ISECT_WAVES
 #define RT_ISECT_WAVES 3
 #endif
-// NOTE: k_wf_shade deliberately has NO waves-per-SIMD hint: with `__launch_bounds__(256, 3)` hipcc
-// (ROCm 7.2) produced different Dielectric results (caught by the bit-exact parity tests) and the
-// hint bought no speed (3 -> 4 waves/SIMD: +1 %).
+// NOTE: k_wf_shade deliberately has NO waves-per-SIMD hint: with `__launch_bounds__(256, 3)` and
+// `(256, 4)` hipcc (ROCm 7.2) produced different Dielectric results (caught by the bit-exact parity
+// tests); (256, 4) also spills 240 B/lane to scratch and is 4 % slower.
 
 namespace rt {
 
