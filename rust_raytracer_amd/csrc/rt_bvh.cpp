@@ -169,4 +169,80 @@ BvhBuild build_bvh(const double* positions, const uint32_t* tri_pos, uint32_t n_
     return out;
 }
 
+
+namespace {
+struct Cand {
+    int32_t ref;
+    double lo[3], hi[3];
+    double area() const {
+        double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (!(dx >= 0 && dy >= 0 && dz >= 0)) return -1.0;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+struct Collapser {
+    const BvhBuild& b2;
+    Bvh4Build out;
+    uint32_t build(int32_t n2, uint32_t depth, uint32_t stack_above) {
+        uint32_t idx = uint32_t(out.nodes.size());
+        out.nodes.emplace_back();
+        if (depth + 1 > out.max_depth) out.max_depth = depth + 1;
+        std::vector<Cand> c;
+        auto add_children = [&](int32_t node2) {
+            const BuildNode& n = b2.nodes[size_t(node2)];
+            Cand a{n.c0, {n.lo0[0], n.lo0[1], n.lo0[2]}, {n.hi0[0], n.hi0[1], n.hi0[2]}};
+            Cand b{n.c1, {n.lo1[0], n.lo1[1], n.lo1[2]}, {n.hi1[0], n.hi1[1], n.hi1[2]}};
+            if (a.ref != kEmptyChild) c.push_back(a);
+            if (b.ref != kEmptyChild) c.push_back(b);
+        };
+        add_children(n2);
+        for (;;) {
+            if (c.size() >= 4) break;
+            int best = -1;
+            double best_area = -1.0;
+            for (size_t i = 0; i < c.size(); i++)
+                if (c[i].ref >= 0 && c[i].area() > best_area) { best_area = c[i].area(); best = int(i); }
+            if (best < 0) break;  // only leaves left
+            int32_t expand = c[size_t(best)].ref;
+            c.erase(c.begin() + best);
+            add_children(expand);
+        }
+        uint32_t n_children = uint32_t(c.size());
+        uint32_t stack_here = stack_above + (n_children > 0 ? n_children - 1 : 0);
+        if (stack_here + 1 > out.max_stack) out.max_stack = stack_here + 1;
+        BuildNode4 node{};
+        for (int k = 0; k < 4; k++) {
+            node.child[k] = kEmptyChild;
+            for (int a = 0; a < 3; a++) { node.lo[k][a] = kInf; node.hi[k][a] = -kInf; }
+        }
+        for (uint32_t k = 0; k < n_children; k++) {
+            for (int a = 0; a < 3; a++) { node.lo[k][a] = c[k].lo[a]; node.hi[k][a] = c[k].hi[a]; }
+            node.child[k] = c[k].ref;  // inner refs are patched below
+        }
+        out.nodes[idx] = node;
+        for (uint32_t k = 0; k < n_children; k++)
+            if (c[k].ref >= 0) {
+                uint32_t child_idx = build(c[k].ref, depth + 1, stack_here);
+                out.nodes[idx].child[k] = int32_t(child_idx);
+            }
+        return idx;
+    }
+};
+}  // namespace
+
+Bvh4Build collapse_bvh4(const BvhBuild& b2) {
+    Collapser c{b2, {}};
+    c.out.nodes.reserve(b2.nodes.size() / 2 + 4);
+    c.build(0, 0, 0);
+    for (int a = 0; a < 3; a++) { c.out.root_lo[a] = kInf; c.out.root_hi[a] = -kInf; }
+    const BuildNode4& r = c.out.nodes[0];
+    for (int k = 0; k < 4; k++)
+        if (r.child[k] != kEmptyChild)
+            for (int a = 0; a < 3; a++) {
+                c.out.root_lo[a] = std::min(c.out.root_lo[a], r.lo[k][a]);
+                c.out.root_hi[a] = std::max(c.out.root_hi[a], r.hi[k][a]);
+            }
+    return std::move(c.out);
+}
+
 }  // namespace rt

@@ -25,4 +25,19 @@ struct BvhBuild {
 // positions: n_positions*3 doubles; tri_pos: n_tris*3 indices.  max_leaf in 1..8.
 BvhBuild build_bvh(const double* positions, const uint32_t* tri_pos, uint32_t n_tris, uint32_t max_leaf);
 
+// 4-wide collapse of a BVH2 (same leaves, same triangle order): every node holds up to four
+// children, obtained by repeatedly replacing the inner child of largest surface area by its two
+// children.  One node fetch then decides four boxes: about half the dependent fetches per ray.
+struct BuildNode4 {
+    double lo[4][3], hi[4][3];
+    int32_t child[4];  // same encoding as BuildNode::c0 (inner index into nodes4 / leaf code / kEmptyChild)
+};
+struct Bvh4Build {
+    std::vector<BuildNode4> nodes;  // nodes[0] is the root
+    uint32_t max_depth = 0;         // inner levels
+    uint32_t max_stack = 0;         // worst-case traversal stack entries (sum over a root-leaf path of children-1) + 1
+    double root_lo[3], root_hi[3];
+};
+Bvh4Build collapse_bvh4(const BvhBuild& bvh2);
+
 }  // namespace rt

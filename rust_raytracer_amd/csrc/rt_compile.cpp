@@ -33,6 +33,8 @@ struct Compiler {
     std::map<uint32_t, int32_t> sphere_of_node, plane_of_node, sun_of_node;
     std::map<int32_t, std::pair<uint32_t, uint32_t>> mesh_geometry;  // RtMesh index -> (node_base, tri_base)
     std::map<int32_t, uint32_t> mesh_depth;
+    std::map<int32_t, uint32_t> mesh_node4_base;
+    std::map<int32_t, Bounds<double>> mesh_box;
     std::map<int32_t, int32_t> xform_of;             // RtTransform index -> xforms index
 
     bool fail(int st, const std::string& msg) {
@@ -126,12 +128,14 @@ struct Compiler {
         return xform_of[t] = int32_t(out.xforms.size()) - 1;
     }
 
-    bool mesh_geometry_for(int32_t mi, uint32_t* node_base, uint32_t* tri_base, uint32_t* depth) {
+    bool mesh_geometry_for(int32_t mi, uint32_t* node_base, uint32_t* tri_base, uint32_t* depth, uint32_t* node4_base, Bounds<double>* box) {
         auto it = mesh_geometry.find(mi);
         if (it != mesh_geometry.end()) {
             *node_base = it->second.first;
             *tri_base = it->second.second;
             *depth = mesh_depth[mi];
+            *node4_base = mesh_node4_base[mi];
+            *box = mesh_box[mi];
             return true;
         }
         const RtMesh& m = d.meshes[mi];
@@ -143,6 +147,13 @@ struct Compiler {
             if (m.tri_uv && m.tri_uv[i] >= 0 && (uint32_t(m.tri_uv[i]) >= m.n_uvs || !m.uvs)) return fail(RT_E_INVALID, "uv index out of range");
         }
         BvhBuild bvh = build_bvh(m.positions, m.tri_pos, m.n_triangles, 4);
+        Bvh4Build bvh4 = collapse_bvh4(bvh);
+        *node4_base = uint32_t(out.nodes4.size());
+        out.nodes4.insert(out.nodes4.end(), bvh4.nodes.begin(), bvh4.nodes.end());
+        if (bvh4.max_stack > out.max_bvh4_stack) out.max_bvh4_stack = bvh4.max_stack;
+        for (int a = 0; a < 3; a++) { box->lo[a] = bvh4.root_lo[a]; box->hi[a] = bvh4.root_hi[a]; }
+        mesh_node4_base[mi] = *node4_base;
+        mesh_box[mi] = *box;
         *node_base = uint32_t(out.nodes.size());
         *tri_base = uint32_t(out.tris.size());
         *depth = bvh.max_depth;
@@ -216,7 +227,9 @@ struct Compiler {
                 if (n.mesh < 0 || uint32_t(n.mesh) >= d.n_meshes) return fail(RT_E_INVALID, "mesh index out of range");
                 if (!check_material(n.material)) return false;
                 MeshInst mi{};
-                if (!mesh_geometry_for(n.mesh, &mi.node_base, &mi.tri_base, &mi.max_depth)) return false;
+                Bounds<double> mbox;
+                if (!mesh_geometry_for(n.mesh, &mi.node_base, &mi.tri_base, &mi.max_depth, &mi.node4_base, &mbox)) return false;
+                out.mesh_bounds.push_back(mbox);
                 mi.material = n.material;
                 mi.flags = d.meshes[n.mesh].flags & (RT_MESH_FLAT_SHADING | RT_MESH_HIT_BACK_FACES);
                 if (d.meshes[n.mesh].tri_uv) mi.flags |= MESH_HAS_UV;

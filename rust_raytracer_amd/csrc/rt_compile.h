@@ -20,6 +20,9 @@ struct CompiledScene {
     std::vector<SunPrim<double>> suns;
     std::vector<MeshInst> meshes;
     std::vector<BuildNode> nodes;            // all meshes, node indices relative to MeshInst::node_base
+    std::vector<BuildNode4> nodes4;          // 4-wide collapse, relative to MeshInst::node4_base
+    std::vector<Bounds<double>> mesh_bounds; // per MeshInst
+    uint32_t max_bvh4_stack = 1;
     std::vector<TriRec<double>> tris;        // leaf order
     std::vector<TriAttr<double>> attrs;      // same order
     std::vector<MaterialRec> materials;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -266,6 +267,43 @@ struct DeviceScene {
             n.c0 = s.c0;
             n.c1 = s.c1;
         }
+        // 4-wide f32 nodes: pad by 2^-19 x (largest |coordinate| of the mesh), round outward
+        std::vector<BvhNode4f> nodes4(cs.nodes4.size());
+        {
+            size_t inst = 0;
+            std::vector<std::pair<uint32_t, double>> pads;  // (node4_base, pad) per distinct mesh, ascending base
+            for (const MeshInst& mi : cs.meshes) {
+                const Bounds<double>& b = cs.mesh_bounds[inst++];
+                double S = 0.0;
+                for (int a = 0; a < 3; a++) S = std::fmax(S, std::fmax(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
+                if (!std::isfinite(S)) S = 0.0;
+                pads.emplace_back(mi.node4_base, S * (1.0 / 524288.0));
+            }
+            std::sort(pads.begin(), pads.end());
+            size_t pi = 0;
+            for (size_t i = 0; i < nodes4.size(); i++) {
+                while (pi + 1 < pads.size() && pads[pi + 1].first <= i) pi++;
+                const double m = pads.empty() ? 0.0 : pads[pi].second;
+                const BuildNode4& sn = cs.nodes4[i];
+                BvhNode4f& dn = nodes4[i];
+                for (int k = 0; k < 4; k++) {
+                    float* lo[3] = {&dn.lox[k], &dn.loy[k], &dn.loz[k]};
+                    float* hi[3] = {&dn.hix[k], &dn.hiy[k], &dn.hiz[k]};
+                    for (int a = 0; a < 3; a++) {
+                        if (!(sn.lo[k][a] <= sn.hi[k][a])) { *lo[a] = INFINITY; *hi[a] = -INFINITY; }
+                        else { *lo[a] = round_down<float>(sn.lo[k][a] - m); *hi[a] = round_up<float>(sn.hi[k][a] + m); }
+                    }
+                    dn.child[k] = sn.child[k];
+                    dn._pad[k] = 0;
+                }
+            }
+        }
+        std::vector<Bounds<R>> mesh_bounds(cs.mesh_bounds.size());
+        for (size_t i = 0; i < mesh_bounds.size(); i++)
+            for (int a = 0; a < 3; a++) {  // outward: this box only decides which rays are queued for the mesh
+                mesh_bounds[i].lo[a] = round_down<R>(cs.mesh_bounds[i].lo[a]);
+                mesh_bounds[i].hi[a] = round_up<R>(cs.mesh_bounds[i].hi[a]);
+            }
         std::vector<TriRec<R>> tris(cs.tris.size());
         for (size_t i = 0; i < tris.size(); i++) {
             cast_arr(tris[i].v0, cs.tris[i].v0); cast_arr(tris[i].e1, cs.tris[i].e1); cast_arr(tris[i].e2, cs.tris[i].e2);
@@ -302,6 +340,8 @@ struct DeviceScene {
         if ((st = buf.upload(suns, &view.suns)) != RT_OK) return st;
         if ((st = buf.upload(cs.meshes, &view.meshes)) != RT_OK) return st;
         if ((st = buf.upload(nodes, &view.nodes)) != RT_OK) return st;
+        if ((st = buf.upload(nodes4, &view.nodes4)) != RT_OK) return st;
+        if ((st = buf.upload(mesh_bounds, &view.mesh_bounds)) != RT_OK) return st;
         if ((st = buf.upload(tris, &view.tris)) != RT_OK) return st;
         if ((st = buf.upload(attrs, &view.attrs)) != RT_OK) return st;
         if ((st = buf.upload(cs.materials, &view.materials)) != RT_OK) return st;
@@ -337,7 +377,7 @@ struct DeviceScene {
         }
         view.n_lights = int32_t(cs.lights.size());
         view.lights_is_list = cs.lights_is_list;
-        view.stack_entries = int32_t(cs.max_bvh_depth) + 2;
+        view.stack_entries = int32_t(std::max(cs.max_bvh_depth + 2, cs.max_bvh4_stack + 1));
         view.n_ops = int32_t(cs.ops.size());
         // The uploads above went through the null stream (small pageable copies may return once
         // staged); the render kernels run on a NON-BLOCKING stream that is not ordered against it.
@@ -663,7 +703,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     st.node_visits = hc.node_visits;
     st.tri_tests = hc.tri_tests;
     st.prim_tests = hc.prim_tests;
-    st.bytes_node = sizeof(BvhNode<R>);
+    st.bytes_node = split ? sizeof(BvhNode4f) : sizeof(BvhNode<R>);
     st.bytes_tri = sizeof(TriRec<R>);
     st.bytes_attr = sizeof(TriAttr<R>);
     // path state moved by the DOMINANT kernel per ray it traverses: ray (6 R) + bound/op read (R + 4)

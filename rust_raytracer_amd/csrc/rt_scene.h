@@ -73,6 +73,8 @@ struct MeshInst {
     uint32_t flags;      // RT_MESH_* | MESH_HAS_UV
     uint32_t n_tris;
     uint32_t max_depth;
+    uint32_t node4_base;  // first BvhNode4f of this mesh in nodes4[]
+    uint32_t _pad;
 };
 constexpr uint32_t MESH_HAS_UV = 0x100u;
 
@@ -84,6 +86,17 @@ template <typename R>
 struct alignas(sizeof(R) == 8 ? 128 : 64) BvhNode {
     R lo0[3], hi0[3], lo1[3], hi1[3];
     int32_t c0, c1;
+};
+
+// 4-wide node with CONSERVATIVE f32 child boxes (structure of arrays over the four children; 128 B =
+// one cache line).  Boxes only cull: they are padded by 2^-19 x (largest |coordinate| of the mesh) and
+// rounded outward, which covers every rounding error of the f32 slab test for rays whose origin has
+// been moved onto the root box (rt_wavefront.h, k_wf_mesh), so no triangle the exact test in R would
+// hit is ever skipped.  Used by the wavefront mesh kernel for both arithmetic types.
+struct alignas(128) BvhNode4f {
+    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+    int32_t child[4];  // >= 0 inner node (relative to node4_base), < 0 leaf code, kEmptyChild
+    uint32_t _pad[4];
 };
 
 // Triangle record for the intersection test: v0 and the two edges (mesh.rs:69-70 computes the
@@ -150,6 +163,8 @@ struct SceneView {
     const SunPrim<R>* suns;
     const MeshInst* meshes;
     const BvhNode<R>* nodes;
+    const BvhNode4f* nodes4;       // 4-wide f32 nodes (wavefront mesh kernel)
+    const Bounds<R>* mesh_bounds;  // per mesh instance: exact box of its triangles (object space)
     const TriRec<R>* tris;
     const TriAttr<R>* attrs;
     const MaterialRec* materials;

@@ -448,25 +448,21 @@ __global__ void __launch_bounds__(256) k_wf_prims(SceneView<R> sc_g, WfPool<R> p
         pool.ht[slot] = best.t; pool.hu[slot] = best.u; pool.hv[slot] = best.v;
         pool.hpc[slot] = best.pc; pool.htri[slot] = best.tri;
         if (mesh_reached) {
-            // does the ray enter the mesh's root box inside (t_lo, best.t]?  (culling only: conservative)
-            const MeshInst& mi = sc.meshes[sc.ops[mesh_pc].arg];
-            const BvhNode<R>& root = sc.nodes[mi.node_base];
+            // does the ray enter the mesh's box inside (t_lo, best.t]?  (culling only: conservative)
+            const Bounds<R>& rb = sc.mesh_bounds[sc.ops[mesh_pc].arg];
             const R big = sizeof(R) == 8 ? R(1e150) : R(1e18);
             V3<R> inv = {fabs(mesh_ray.inv.x) > big ? copysign(big, mesh_ray.inv.x) : mesh_ray.inv.x,
                          fabs(mesh_ray.inv.y) > big ? copysign(big, mesh_ray.inv.y) : mesh_ray.inv.y,
                          fabs(mesh_ray.inv.z) > big ? copysign(big, mesh_ray.inv.z) : mesh_ray.inv.z};
-            V3<R> oi = mesh_ray.o * inv;
-            R lo[3], hi[3];
-            for (int a = 0; a < 3; a++) {  // union of the two child boxes of the root
-                lo[a] = fmin(root.lo0[a], root.c1 == kEmptyChild ? root.lo0[a] : root.lo1[a]);
-                hi[a] = fmax(root.hi0[a], root.c1 == kEmptyChild ? root.hi0[a] : root.hi1[a]);
-            }
-            R t0x = lo[0] * inv.x - oi.x, t1x = hi[0] * inv.x - oi.x;
-            R t0y = lo[1] * inv.y - oi.y, t1y = hi[1] * inv.y - oi.y;
-            R t0z = lo[2] * inv.z - oi.z, t1z = hi[2] * inv.z - oi.z;
+            // a few ulps of slack on the box: this test must never be stricter than the traversal
+            const R eps = Lim<R>::eps() * R(16);
+            R t0x = (rb.lo[0] - fabs(rb.lo[0]) * eps - mesh_ray.o.x) * inv.x, t1x = (rb.hi[0] + fabs(rb.hi[0]) * eps - mesh_ray.o.x) * inv.x;
+            R t0y = (rb.lo[1] - fabs(rb.lo[1]) * eps - mesh_ray.o.y) * inv.y, t1y = (rb.hi[1] + fabs(rb.hi[1]) * eps - mesh_ray.o.y) * inv.y;
+            R t0z = (rb.lo[2] - fabs(rb.lo[2]) * eps - mesh_ray.o.z) * inv.z, t1z = (rb.hi[2] + fabs(rb.hi[2]) * eps - mesh_ray.o.z) * inv.z;
             R tn = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmax(fmin(t0z, t1z), t_lo));
             R tf = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmin(fmax(t0z, t1z), best.t));
-            to_mesh = (tn <= tf) && root.c0 != kEmptyChild;
+            tf = tf + fabs(tf) * eps;
+            to_mesh = (tn <= tf) && rb.lo[0] <= rb.hi[0];
         }
     }
     lds_append(to_mesh, slot, mesh_list, &lc[0]);
@@ -487,6 +483,13 @@ __global__ void __launch_bounds__(256) k_wf_prims(SceneView<R> sc_g, WfPool<R> p
     }
 }
 
+// f32 value that is certainly >= x (x finite or +inf): round to nearest, then add a relative margin.
+RT_DEV float f32_at_least(double x) {
+    float f = float(x);
+    return f + fabsf(f) * 9.5367431640625e-7f + 1e-30f;  // 2^-20 relative
+}
+RT_DEV float f32_at_least(float x) { return x + fabsf(x) * 9.5367431640625e-7f + 1e-30f; }
+
 template <typename R, bool STATS>
 __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc, WfPool<R> pool, const uint32_t* __restrict__ mesh_queue,
                                                                  WfCounters* __restrict__ ctr, DeviceCounters* counters,
@@ -498,7 +501,8 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc
     const R t_lo = R(0.001);
     const Op mop = sc.ops[mesh_pc];
     const MeshInst mi = sc.meshes[mop.arg];
-    const BvhNode<R>* nodes = sc.nodes + mi.node_base;
+    const Bounds<R> rb = sc.mesh_bounds[mop.arg];
+    const BvhNode4f* nodes = sc.nodes4 + mi.node4_base;
     const TriRec<R>* tris = sc.tris + mi.tri_base;
     const bool hit_back = (mi.flags & RT_MESH_HIT_BACK_FACES) != 0;
     const R big = sizeof(R) == 8 ? R(1e150) : R(1e18);
@@ -509,9 +513,11 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc
     bool found = false;      // a triangle closer than the other primitives' hit was found
     WaveRange range;
     uint32_t slot = 0;
-    V3<R> o{}, d{}, inv{}, oi{};
-    R t_max = R(0), hit_u = R(0), hit_v = R(0);
+    V3<R> o{}, d{};          // object-space ray, exact: used by the triangle tests
+    R t_max = R(0), hit_u = R(0), hit_v = R(0), t_shift = R(0);
     int32_t hit_tri = -1;
+    // f32 culling ray: origin moved onto the mesh box (so |origin| <= mesh extent), t measured from there
+    float ivx = 0.f, ivy = 0.f, ivz = 0.f, oix = 0.f, oiy = 0.f, oiz = 0.f, tmax32 = 0.f;
     int32_t node = 0;        // >= 0 inner node, < 0 leaf
     int sp = 0;
 
@@ -527,15 +533,29 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc
                 Ray<R> ray = ray_in_chain(sc, wray, mop.chain);
                 o = ray.o;
                 d = ray.d;
-                inv = {fabs(ray.inv.x) > big ? copysign(big, ray.inv.x) : ray.inv.x,
-                       fabs(ray.inv.y) > big ? copysign(big, ray.inv.y) : ray.inv.y,
-                       fabs(ray.inv.z) > big ? copysign(big, ray.inv.z) : ray.inv.z};
-                oi = o * inv;
+                V3<R> inv = {fabs(ray.inv.x) > big ? copysign(big, ray.inv.x) : ray.inv.x,
+                             fabs(ray.inv.y) > big ? copysign(big, ray.inv.y) : ray.inv.y,
+                             fabs(ray.inv.z) > big ? copysign(big, ray.inv.z) : ray.inv.z};
+                // entry into the mesh box (>= 0); the culling origin is o + d * t_shift
+                R e0x = (rb.lo[0] - o.x) * inv.x, e1x = (rb.hi[0] - o.x) * inv.x;
+                R e0y = (rb.lo[1] - o.y) * inv.y, e1y = (rb.hi[1] - o.y) * inv.y;
+                R e0z = (rb.lo[2] - o.z) * inv.z, e1z = (rb.hi[2] - o.z) * inv.z;
+                t_shift = fmax(fmax(fmin(e0x, e1x), fmin(e0y, e1y)), fmax(fmin(e0z, e1z), R(0)));
+                if (!(t_shift < Lim<R>::inf())) t_shift = R(0);
+                V3<R> oc = o + d * t_shift;
+                const float big32 = 1e18f;
+                float dx32 = float(d.x), dy32 = float(d.y), dz32 = float(d.z);
+                ivx = 1.0f / dx32; ivy = 1.0f / dy32; ivz = 1.0f / dz32;
+                ivx = fabsf(ivx) > big32 ? copysignf(big32, ivx) : ivx;
+                ivy = fabsf(ivy) > big32 ? copysignf(big32, ivy) : ivy;
+                ivz = fabsf(ivz) > big32 ? copysignf(big32, ivz) : ivz;
+                oix = float(oc.x) * ivx; oiy = float(oc.y) * ivy; oiz = float(oc.z) * ivz;
                 // The other primitives' closest hit bounds the search.  At exactly equal t the op that
                 // comes first in program order wins: if that is the mesh, t == bound must be accepted.
                 R bound = pool.ht[slot];
                 int32_t bpc = pool.hpc[slot];
                 t_max = (bpc > mesh_pc && bound < Lim<R>::inf()) ? nextafter(bound, Lim<R>::inf()) : bound;
+                tmax32 = f32_at_least(t_max - t_shift);
                 found = false;
                 hit_tri = -1;
                 node = 0;
@@ -555,31 +575,41 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc
             // a few stragglers do not keep a wave full of ready leaves waiting
             if (uint32_t(__popcll(inner)) < inner_min && __ballot(has && node < 0) != 0ull) break;
             if (has && node >= 0) {
-                const BvhNode<R>& nd = nodes[node];
+                const BvhNode4f& nd = nodes[node];
                 if (STATS) cnt.node_visits++;
-                R t0x = nd.lo0[0] * inv.x - oi.x, t1x = nd.hi0[0] * inv.x - oi.x;
-                R t0y = nd.lo0[1] * inv.y - oi.y, t1y = nd.hi0[1] * inv.y - oi.y;
-                R t0z = nd.lo0[2] * inv.z - oi.z, t1z = nd.hi0[2] * inv.z - oi.z;
-                R near0 = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmax(fmin(t0z, t1z), t_lo));
-                R far0 = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmin(fmax(t0z, t1z), t_max));
-                R s0x = nd.lo1[0] * inv.x - oi.x, s1x = nd.hi1[0] * inv.x - oi.x;
-                R s0y = nd.lo1[1] * inv.y - oi.y, s1y = nd.hi1[1] * inv.y - oi.y;
-                R s0z = nd.lo1[2] * inv.z - oi.z, s1z = nd.hi1[2] * inv.z - oi.z;
-                R near1 = fmax(fmax(fmin(s0x, s1x), fmin(s0y, s1y)), fmax(fmin(s0z, s1z), t_lo));
-                R far1 = fmin(fmin(fmax(s0x, s1x), fmax(s0y, s1y)), fmin(fmax(s0z, s1z), t_max));
-                int32_t c0 = nd.c0, c1 = nd.c1;
-                bool h0 = (near0 <= far0) && c0 != kEmptyChild;
-                bool h1 = (near1 <= far1) && c1 != kEmptyChild;
-                if (h0 && h1) {
-                    bool first0 = near0 <= near1;
-                    stack[sp * stride] = first0 ? c1 : c0;
-                    sp++;
-                    node = first0 ? c0 : c1;
-                } else if (h0) node = c0;
-                else if (h1) node = c1;
-                else if (sp > 0) { sp--; node = stack[sp * stride]; }
-                else { has = false; }  // traversal finished (result written below)
-                if (!has) {
+                float nr[4];
+                int32_t ch[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float t0x = nd.lox[k] * ivx - oix, t1x = nd.hix[k] * ivx - oix;
+                    float t0y = nd.loy[k] * ivy - oiy, t1y = nd.hiy[k] * ivy - oiy;
+                    float t0z = nd.loz[k] * ivz - oiz, t1z = nd.hiz[k] * ivz - oiz;
+                    float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+                    float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax32));
+                    ch[k] = nd.child[k];
+                    bool h = (tn <= tf) && ch[k] != kEmptyChild;
+                    nr[k] = h ? tn : __builtin_huge_valf();
+                }
+                // sort the four (entry distance, child) pairs, nearest first (5 compare-exchanges)
+#define RT_CE(a, b)                                                   \
+    if (nr[a] > nr[b]) {                                              \
+        float tn_ = nr[a]; nr[a] = nr[b]; nr[b] = tn_;                \
+        int32_t tc_ = ch[a]; ch[a] = ch[b]; ch[b] = tc_;              \
+    }
+                RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2) RT_CE(1, 3) RT_CE(1, 2)
+#undef RT_CE
+                const float miss = __builtin_huge_valf();
+                if (nr[0] < miss) {
+                    // farthest first, so that the nearest remaining child is popped first
+                    if (nr[3] < miss) { stack[sp * stride] = ch[3]; sp++; }
+                    if (nr[2] < miss) { stack[sp * stride] = ch[2]; sp++; }
+                    if (nr[1] < miss) { stack[sp * stride] = ch[1]; sp++; }
+                    node = ch[0];
+                } else if (sp > 0) {
+                    sp--;
+                    node = stack[sp * stride];
+                } else {
+                    has = false;  // traversal finished
                     if (found) {
                         pool.ht[slot] = t_max; pool.hu[slot] = hit_u; pool.hv[slot] = hit_v;
                         pool.hpc[slot] = mesh_pc; pool.htri[slot] = hit_tri;
@@ -587,7 +617,7 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc
                 }
             }
         }
-        // ---- leaves: every lane that holds one tests its triangles, then pops ----
+        // ---- leaves: every lane that holds one tests its triangles in exact R arithmetic, then pops ----
         if (has && node < 0) {
             uint32_t code = uint32_t(~node);
             uint32_t first = code >> 3, count = (code & 7u) + 1u;
@@ -610,6 +640,7 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc
                 if (t <= t_lo || t_max <= t) continue;
                 t_max = t; hit_u = u; hit_v = v; hit_tri = int32_t(mi.tri_base + first + k);
                 found = true;
+                tmax32 = f32_at_least(t_max - t_shift);
             }
             if (sp > 0) { sp--; node = stack[sp * stride]; }
             else {

@@ -153,10 +153,10 @@ def test_stats_counters_and_collect_flag(dev):
     q.pipeline = api.RT_PIPELINE_MEGAKERNEL
     scene.render(hs.camera, q)
     sm = scene.stats()
-    # same rays; the split wavefront intersect tests the other primitives first, so the mesh
-    # traversal starts with a tighter interval: never more BVH work than the in-order megakernel
+    # same rays; the wavefront mesh kernel walks the 4-wide tree (about half the node fetches of the
+    # megakernel's BVH2) with padded f32 boxes (a few more leaves than the exact boxes)
     assert sm.rays == st.rays
-    assert st.node_visits <= sm.node_visits and st.tri_tests <= sm.tri_tests
+    assert st.node_visits < sm.node_visits and st.tri_tests <= 1.3 * sm.tri_tests
     p.collect_stats = 0
     np.testing.assert_array_equal(scene.render(hs.camera, p), with_stats)   # counting never changes pixels
     _, ost = pyoracle.render(hs.desc, hs.camera, hs.params)
