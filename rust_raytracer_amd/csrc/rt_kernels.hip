@@ -555,7 +555,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     const uint32_t T = p.thread_count;
     const uint64_t per_replica = uint64_t(strata) * npix;
     // pool size: enough paths to keep every CU busy for several rounds per launch
-    uint32_t capacity = env_u32("RT_WF_POOL", 1u << 24);  // 16M paths (~2.7 GB of f64 state); measured: 2M 260, 8M 350, 16M 362 Msamples/s
+    uint32_t capacity = env_u32("RT_WF_POOL", 1u << 25);  // 32M paths (5.5 GB of f64 state); measured at full size: 2M 322, 8M 377, 16M 393, 32M 404 Msamples/s
     if (uint64_t(capacity) > per_replica * T) capacity = uint32_t(per_replica * T);
     if (capacity < 64) capacity = 64;
     if (int st = wf_ensure<R>(s, capacity)) return st;
@@ -629,6 +629,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
         grp.tid0 = t0;
         grp.strata = strata;
         uint32_t first = uint32_t(std::min<uint64_t>(capacity, grp.total));
+        pool.capacity = first;  // slots in use by this group: the kernels address slots directly while all of them are queued
         WfCounters init{};
         init.n_in = first;
         init.n_out = 0;

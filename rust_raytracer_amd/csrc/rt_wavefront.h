@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<
         if (!exhausted && n_idle >= refill_min) {
             uint32_t my = 0;
             if (wave_fetch(range, idle, &ctr->cursor, n, exhausted, my)) {
-                slot = queue[my];
+                slot = n == pool.capacity ? my : queue[my];  // full pool: identity order (see k_wf_shade)
                 wray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
                 cur = wray;
                 best.t = Lim<R>::inf(); best.pc = -1; best.tri = -1; best.u = R(0); best.v = R(0);
@@ -374,6 +374,7 @@ __global__ void __launch_bounds__(256) k_wf_prims(SceneView<R> sc_g, WfPool<R> p
     if constexpr (LDS) sc = scene_tables_to_lds(sc_g, tables);
     else __syncthreads();
     const uint32_t n = ctr->n_in;
+    const bool full = n == pool.capacity;
     const uint32_t begin = blockIdx.x * WF_CHUNK;
     const uint32_t end = min(n, begin + WF_CHUNK);
     const R t_lo = R(0.001);
@@ -384,7 +385,7 @@ __global__ void __launch_bounds__(256) k_wf_prims(SceneView<R> sc_g, WfPool<R> p
     bool to_mesh = false;
     uint32_t slot = 0;
     if (active) {
-        slot = queue[i];
+        slot = full ? i : queue[i];
         const Ray<R> wray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
         Ray<R> cur = wray;
         Ray<R> mesh_ray = wray;
@@ -676,6 +677,10 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneView<R> sc_g, CameraView<
     if constexpr (LDS) sc = scene_tables_to_lds(sc_g, tables);
     else __syncthreads();
     const uint32_t n = ctr->n_in;
+    // While samples remain every finished path restarts in place, so ALL slots are queued: the order of
+    // the queue is then irrelevant and slot = queue position makes every state access coalesced (the
+    // compacted queue is a near-random permutation after a few iterations: 64 lines per wave load).
+    const bool full = n == pool.capacity;
     const uint32_t begin = blockIdx.x * WF_CHUNK;
     const uint32_t end = min(n, begin + WF_CHUNK);
     LaneCounters cnt;
@@ -686,7 +691,7 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneView<R> sc_g, CameraView<
     bool alive = false;
     uint32_t slot = 0;
     if (active) {
-        slot = queue_in[i];
+        slot = full ? i : queue_in[i];
         PathState<R> ps;
         ps.ray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
         ps.throughput = mk<R>(pool.tr[slot], pool.tg[slot], pool.tb[slot]);
