@@ -4,6 +4,7 @@
 #include "rt_compile.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
@@ -146,7 +147,9 @@ struct Compiler {
             if (m.tri_pos[i] >= m.n_positions || m.tri_nrm[i] >= m.n_normals) return fail(RT_E_INVALID, "triangle index out of range");
             if (m.tri_uv && m.tri_uv[i] >= 0 && (uint32_t(m.tri_uv[i]) >= m.n_uvs || !m.uvs)) return fail(RT_E_INVALID, "uv index out of range");
         }
-        BvhBuild bvh = build_bvh(m.positions, m.tri_pos, m.n_triangles, 4);
+        uint32_t max_leaf = 4;  // triangles per leaf (1..8); RT_BVH_MAX_LEAF overrides for experiments
+        if (const char* e = std::getenv("RT_BVH_MAX_LEAF")) { int v = std::atoi(e); if (v >= 1 && v <= 8) max_leaf = uint32_t(v); }
+        BvhBuild bvh = build_bvh(m.positions, m.tri_pos, m.n_triangles, max_leaf);
         Bvh4Build bvh4 = collapse_bvh4(bvh);
         *node4_base = uint32_t(out.nodes4.size());
         out.nodes4.insert(out.nodes4.end(), bvh4.nodes.begin(), bvh4.nodes.end());

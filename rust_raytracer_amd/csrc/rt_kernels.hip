@@ -406,6 +406,8 @@ struct RtScene {
         void* pool_view = nullptr;     // host copy of WfPool<R>
         uint32_t* queue[2] = {nullptr, nullptr};
         uint32_t* mesh_queue = nullptr;
+        void* mesh_spill = nullptr;        // k_wf_mesh: stack levels beyond the LDS part
+        size_t mesh_spill_bytes = 0;
         rt::WfCounters* d_ctr = nullptr;
         rt::WfCounters* h_ctr = nullptr;   // pinned
         double* sample_L = nullptr;
@@ -604,12 +606,26 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
         if (n_mesh_ops != 1 || env_u32("RT_WF_SPLIT", 1) == 0) mesh_pc = -1;
     }
     const bool split = mesh_pc >= 0;
+    // k_wf_mesh keeps (child, entry distance) pairs: a shallow LDS part (occupancy) + a global spill part
+    const int mesh_levels = int(s->compiled.max_bvh4_stack) + 1;
+    const int lds_levels = std::min<int>(mesh_levels, int(env_u32("RT_WF_LDS_LEVELS", 12)));
+    const size_t lds_mesh = size_t(lds_levels) * 256 * sizeof(uint2);
     if (split) {
-        if (stats) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_mesh<R, true>, 256, lds));
-        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_mesh<R, false>, 256, lds));
+        if (stats) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_mesh<R, true>, 256, lds_mesh));
+        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_mesh<R, false>, 256, lds_mesh));
         if (blocks_per_cu < 1) blocks_per_cu = 1;
     }
     const uint32_t isect_blocks = uint32_t(n_cu) * uint32_t(blocks_per_cu);
+    if (split) {
+        size_t need = size_t(std::max(mesh_levels - lds_levels, 1)) * isect_blocks * 256 * sizeof(uint2);
+        if (need > w.mesh_spill_bytes) {
+            if (w.mesh_spill) (void)hipFree(w.mesh_spill);
+            w.mesh_spill = nullptr;
+            w.mesh_spill_bytes = 0;
+            HIP_TRY(hipMalloc(&w.mesh_spill, need));
+            w.mesh_spill_bytes = need;
+        }
+    }
     const uint32_t refill_min = env_u32("RT_WF_REFILL", 32);  // measured optimum (64 = no refill: -20 %)
     const uint32_t inner_min = env_u32("RT_WF_INNER_MIN", 16);
     // small tables staged in LDS by the prims / shade kernels when they fit
@@ -651,9 +667,9 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
 #undef RT_LAUNCH_PRIMS
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
                     if (stats)
-                        hipLaunchKernelGGL((k_wf_mesh<R, true>), dim3(isect_blocks), dim3(256), lds, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc);
+                        hipLaunchKernelGGL((k_wf_mesh<R, true>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels);
                     else
-                        hipLaunchKernelGGL((k_wf_mesh<R, false>), dim3(isect_blocks), dim3(256), lds, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc);
+                        hipLaunchKernelGGL((k_wf_mesh<R, false>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels);
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 } else {
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
@@ -697,6 +713,14 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     st.kernel_ms = ms;
     st.traversal_kernel_ms = isect_ms;
     st.n_launches = isect_launches;
+    if (stats && split && env_u32("RT_WF_DEBUG", 0)) {
+        auto pct = [](unsigned long long lanes, unsigned long long waves) { return waves ? 100.0 * double(lanes) / (64.0 * double(waves)) : 0.0; };
+        std::fprintf(stderr,
+                     "[k_wf_mesh] rays %llu  node code: %llu wave iterations, %.1f %% lanes active;  triangle code: %llu, %.1f %%;  "
+                     "refill: %llu, %.1f %%;  stack entries culled on pop %llu\n",
+                     hc.mesh_rays, hc.node_wave_iters, pct(hc.node_visits, hc.node_wave_iters), hc.tri_wave_iters,
+                     pct(hc.tri_tests, hc.tri_wave_iters), hc.refill_wave_iters, pct(hc.refill_lanes, hc.refill_wave_iters), hc.pops_culled);
+    }
     st.pipeline_used = RT_PIPELINE_WAVEFRONT;
     st.samples = npix * uint64_t(pv.spp);
     st.rays = hc.rays;
@@ -775,6 +799,7 @@ void rt_scene_destroy(RtScene* s) {
     if (s->wf.queue[0]) (void)hipFree(s->wf.queue[0]);
     if (s->wf.queue[1]) (void)hipFree(s->wf.queue[1]);
     if (s->wf.mesh_queue) (void)hipFree(s->wf.mesh_queue);
+    if (s->wf.mesh_spill) (void)hipFree(s->wf.mesh_spill);
     if (s->wf.d_ctr) (void)hipFree(s->wf.d_ctr);
     if (s->wf.h_ctr) (void)hipHostFree(s->wf.h_ctr);
     if (s->wf.sample_L) (void)hipFree(s->wf.sample_L);

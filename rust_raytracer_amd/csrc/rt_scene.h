@@ -202,6 +202,9 @@ struct ParamsView {
 
 struct DeviceCounters {
     unsigned long long rays, mesh_rays, node_visits, tri_tests, prim_tests;
+    // k_wf_mesh lane utilisation (collect_stats): wave-level iterations of the node / triangle / refill code and
+    // the lanes that were active in them (utilisation = lanes / (64 * waves)); printed with RT_WF_DEBUG=1
+    unsigned long long node_wave_iters, tri_wave_iters, refill_wave_iters, refill_lanes, pops_culled;
 };
 
 }  // namespace rt

@@ -25,6 +25,9 @@
 #ifndef RT_ISECT_WAVES
 #define RT_ISECT_WAVES 3
 #endif
+#ifndef RT_MESH_WAVES
+#define RT_MESH_WAVES 5
+#endif
 // NOTE: k_wf_shade deliberately has NO waves-per-SIMD hint: with `__launch_bounds__(256, 3)` and
 // `(256, 4)` hipcc (ROCm 7.2) produced different Dielectric results (caught by the bit-exact parity
 // tests); (256, 4) also spills 240 B/lane to scratch and is 4 % slower.
@@ -491,13 +494,37 @@ RT_DEV float f32_at_least(double x) {
 }
 RT_DEV float f32_at_least(float x) { return x + fabsf(x) * 9.5367431640625e-7f + 1e-30f; }
 
+// Per-lane traversal stack of k_wf_mesh: entries are (child reference, f32 entry distance of its box).
+// The first `lds_levels` levels live in LDS (`[level][lane]`, conflict-free 8-B accesses), deeper levels in
+// a private global spill area (`[level][global lane]`, coalesced).  A shallow LDS part keeps 5 waves/SIMD
+// resident; the spill part is touched by a few percent of the pushes (worst case = BVH4 max_stack).
+struct MeshStack {
+    uint2* lds;        // + threadIdx.x
+    uint2* spill;      // + global lane
+    int lds_levels;
+    uint32_t spill_stride;
+    RT_DEV void put(int sp, int32_t child, float dist) const {
+        uint2 e = make_uint2(uint32_t(child), __float_as_uint(dist));
+        if (sp < lds_levels) lds[sp * 256] = e;
+        else spill[size_t(sp - lds_levels) * spill_stride] = e;
+    }
+    RT_DEV uint2 get(int sp) const {
+        if (sp < lds_levels) return lds[sp * 256];
+        return spill[size_t(sp - lds_levels) * spill_stride];
+    }
+};
+
 template <typename R, bool STATS>
-__global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc, WfPool<R> pool, const uint32_t* __restrict__ mesh_queue,
+__global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc, WfPool<R> pool, const uint32_t* __restrict__ mesh_queue,
                                                                  WfCounters* __restrict__ ctr, DeviceCounters* counters,
-                                                                 uint32_t refill_min, uint32_t inner_min, int32_t mesh_pc) {
-    extern __shared__ int lds_stack[];
-    int* stack = lds_stack + threadIdx.x;
-    const int stride = int(blockDim.x);
+                                                                 uint32_t refill_min, uint32_t inner_min, int32_t mesh_pc,
+                                                                 uint2* __restrict__ spill, int lds_levels) {
+    extern __shared__ uint2 lds_stack2[];
+    MeshStack stk;
+    stk.lds = lds_stack2 + threadIdx.x;
+    stk.spill = spill + (size_t(blockIdx.x) * blockDim.x + threadIdx.x);
+    stk.lds_levels = lds_levels;
+    stk.spill_stride = gridDim.x * blockDim.x;
     const uint32_t n = ctr->n_mesh;
     const R t_lo = R(0.001);
     const Op mop = sc.ops[mesh_pc];
@@ -509,6 +536,7 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc
     const R big = sizeof(R) == 8 ? R(1e150) : R(1e18);
 
     LaneCounters cnt;
+    uint32_t w_node = 0, w_tri = 0, w_refill = 0, l_refill = 0, l_culled = 0;  // STATS: see DeviceCounters
     bool has = false;
     bool exhausted = false;
     bool found = false;      // a triangle closer than the other primitives' hit was found
@@ -519,8 +547,31 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc
     int32_t hit_tri = -1;
     // f32 culling ray: origin moved onto the mesh box (so |origin| <= mesh extent), t measured from there
     float ivx = 0.f, ivy = 0.f, ivz = 0.f, oix = 0.f, oiy = 0.f, oiz = 0.f, tmax32 = 0.f;
+    uint32_t nearx = 0, neary = 1, nearz = 2;  // float4 index of the near plane array per axis (lo: 0,1,2 / hi: 3,4,5)
     int32_t node = 0;        // >= 0 inner node, < 0 leaf
     int sp = 0;
+
+    // Pops entries until one whose box can still contain a closer hit is found (entry distance <= current
+    // bound); a lane whose stack runs empty has finished and writes its hit.
+    auto pop_next = [&]() {
+        for (;;) {
+            if (sp == 0) {
+                has = false;
+                if (found) {
+                    pool.ht[slot] = t_max; pool.hu[slot] = hit_u; pool.hv[slot] = hit_v;
+                    pool.hpc[slot] = mesh_pc; pool.htri[slot] = hit_tri;
+                }
+                return;
+            }
+            sp--;
+            uint2 e = stk.get(sp);
+            if (__uint_as_float(e.y) <= tmax32) {
+                node = int32_t(e.x);
+                return;
+            }
+            if (STATS) l_culled++;
+        }
+    };
 
     for (;;) {
         // ---- refill ----
@@ -528,7 +579,9 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc
         uint32_t n_idle = uint32_t(__popcll(idle));
         if (!exhausted && n_idle >= refill_min) {
             uint32_t my = 0;
+            if (STATS) w_refill++;
             if (wave_fetch(range, idle, &ctr->cursor, n, exhausted, my)) {
+                if (STATS) l_refill++;
                 slot = mesh_queue[my];
                 Ray<R> wray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
                 Ray<R> ray = ray_in_chain(sc, wray, mop.chain);
@@ -551,6 +604,11 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc
                 ivy = fabsf(ivy) > big32 ? copysignf(big32, ivy) : ivy;
                 ivz = fabsf(ivz) > big32 ? copysignf(big32, ivz) : ivz;
                 oix = float(oc.x) * ivx; oiy = float(oc.y) * ivy; oiz = float(oc.z) * ivz;
+                // with lo <= hi the nearer plane of an axis is `lo` for a non-negative inverse direction, `hi`
+                // otherwise: lo * iv vs hi * iv are then already ordered and the per-box min/max disappear
+                nearx = ivx < 0.0f ? 3u : 0u;
+                neary = ivy < 0.0f ? 4u : 1u;
+                nearz = ivz < 0.0f ? 5u : 2u;
                 // The other primitives' closest hit bounds the search.  At exactly equal t the op that
                 // comes first in program order wins: if that is the mesh, t == bound must be accepted.
                 R bound = pool.ht[slot];
@@ -575,19 +633,23 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc
             if (inner == 0ull) break;
             // a few stragglers do not keep a wave full of ready leaves waiting
             if (uint32_t(__popcll(inner)) < inner_min && __ballot(has && node < 0) != 0ull) break;
+            if (STATS) w_node++;
             if (has && node >= 0) {
-                const BvhNode4f& nd = nodes[node];
+                const float4* nd = reinterpret_cast<const float4*>(nodes + node);
                 if (STATS) cnt.node_visits++;
+                const float4 nx = nd[nearx], fx = nd[3u - nearx];
+                const float4 ny = nd[neary], fy = nd[5u - neary];
+                const float4 nz = nd[nearz], fz = nd[7u - nearz];
+                const int4 cc = *reinterpret_cast<const int4*>(nd + 6);
                 float nr[4];
-                int32_t ch[4];
+                int32_t ch[4] = {cc.x, cc.y, cc.z, cc.w};
+                const float nxa[4] = {nx.x, nx.y, nx.z, nx.w}, fxa[4] = {fx.x, fx.y, fx.z, fx.w};
+                const float nya[4] = {ny.x, ny.y, ny.z, ny.w}, fya[4] = {fy.x, fy.y, fy.z, fy.w};
+                const float nza[4] = {nz.x, nz.y, nz.z, nz.w}, fza[4] = {fz.x, fz.y, fz.z, fz.w};
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    float t0x = nd.lox[k] * ivx - oix, t1x = nd.hix[k] * ivx - oix;
-                    float t0y = nd.loy[k] * ivy - oiy, t1y = nd.hiy[k] * ivy - oiy;
-                    float t0z = nd.loz[k] * ivz - oiz, t1z = nd.hiz[k] * ivz - oiz;
-                    float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
-                    float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax32));
-                    ch[k] = nd.child[k];
+                    float tn = fmaxf(fmaxf(nxa[k] * ivx - oix, nya[k] * ivy - oiy), fmaxf(nza[k] * ivz - oiz, 0.0f));
+                    float tf = fminf(fminf(fxa[k] * ivx - oix, fya[k] * ivy - oiy), fminf(fza[k] * ivz - oiz, tmax32));
                     bool h = (tn <= tf) && ch[k] != kEmptyChild;
                     nr[k] = h ? tn : __builtin_huge_valf();
                 }
@@ -602,23 +664,21 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc
                 const float miss = __builtin_huge_valf();
                 if (nr[0] < miss) {
                     // farthest first, so that the nearest remaining child is popped first
-                    if (nr[3] < miss) { stack[sp * stride] = ch[3]; sp++; }
-                    if (nr[2] < miss) { stack[sp * stride] = ch[2]; sp++; }
-                    if (nr[1] < miss) { stack[sp * stride] = ch[1]; sp++; }
+                    if (nr[3] < miss) { stk.put(sp, ch[3], nr[3]); sp++; }
+                    if (nr[2] < miss) { stk.put(sp, ch[2], nr[2]); sp++; }
+                    if (nr[1] < miss) { stk.put(sp, ch[1], nr[1]); sp++; }
                     node = ch[0];
-                } else if (sp > 0) {
-                    sp--;
-                    node = stack[sp * stride];
                 } else {
-                    has = false;  // traversal finished
-                    if (found) {
-                        pool.ht[slot] = t_max; pool.hu[slot] = hit_u; pool.hv[slot] = hit_v;
-                        pool.hpc[slot] = mesh_pc; pool.htri[slot] = hit_tri;
-                    }
+                    pop_next();
                 }
             }
         }
         // ---- leaves: every lane that holds one tests its triangles in exact R arithmetic, then pops ----
+        if (STATS) {  // the wave runs the triangle loop as often as its largest leaf needs
+            uint32_t c = (has && node < 0) ? ((uint32_t(~node) & 7u) + 1u) : 0u;
+            for (int off = 32; off > 0; off >>= 1) c = max(c, uint32_t(__shfl_xor(int(c), off)));
+            w_tri += c;
+        }
         if (has && node < 0) {
             uint32_t code = uint32_t(~node);
             uint32_t first = code >> 3, count = (code & 7u) + 1u;
@@ -643,20 +703,21 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_mesh(SceneView<R> sc
                 found = true;
                 tmax32 = f32_at_least(t_max - t_shift);
             }
-            if (sp > 0) { sp--; node = stack[sp * stride]; }
-            else {
-                has = false;
-                if (found) {
-                    pool.ht[slot] = t_max; pool.hu[slot] = hit_u; pool.hv[slot] = hit_v;
-                    pool.hpc[slot] = mesh_pc; pool.htri[slot] = hit_tri;
-                }
-            }
+            pop_next();
         }
     }
     if (STATS) {
         atomicAdd(&counters->mesh_rays, (unsigned long long)cnt.mesh_rays);
         atomicAdd(&counters->node_visits, (unsigned long long)cnt.node_visits);
         atomicAdd(&counters->tri_tests, (unsigned long long)cnt.tri_tests);
+        atomicAdd(&counters->refill_lanes, (unsigned long long)l_refill);
+        atomicAdd(&counters->pops_culled, (unsigned long long)l_culled);
+        uint32_t wn = w_node, wt = w_tri, wr = w_refill;  // wave-uniform
+        if ((threadIdx.x & 63u) == 0) {
+            atomicAdd(&counters->node_wave_iters, (unsigned long long)wn);
+            atomicAdd(&counters->tri_wave_iters, (unsigned long long)wt);
+            atomicAdd(&counters->refill_wave_iters, (unsigned long long)wr);
+        }
     }
 }
 
