@@ -609,7 +609,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     // k_wf_mesh keeps (child, entry distance) pairs: a shallow LDS part (occupancy) + a global spill part
     const int mesh_levels = int(s->compiled.max_bvh4_stack) + 1;
     const int lds_levels = std::min<int>(mesh_levels, int(env_u32("RT_WF_LDS_LEVELS", 12)));
-    const size_t lds_mesh = size_t(lds_levels) * 256 * sizeof(uint2);
+    const size_t lds_mesh = size_t(lds_levels) * 256 * sizeof(uint2) + 4 * kMeshWaveLds<R>;
     if (split) {
         if (stats) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_mesh<R, true>, 256, lds_mesh));
         else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_mesh<R, false>, 256, lds_mesh));

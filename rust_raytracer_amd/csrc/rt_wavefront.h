@@ -26,7 +26,7 @@
 #define RT_ISECT_WAVES 3
 #endif
 #ifndef RT_MESH_WAVES
-#define RT_MESH_WAVES 5
+#define RT_MESH_WAVES 4
 #endif
 // NOTE: k_wf_shade deliberately has NO waves-per-SIMD hint: with `__launch_bounds__(256, 3)` and
 // `(256, 4)` hipcc (ROCm 7.2) produced different Dielectric results (caught by the bit-exact parity
@@ -496,8 +496,9 @@ RT_DEV float f32_at_least(float x) { return x + fabsf(x) * 9.5367431640625e-7f +
 
 // Per-lane traversal stack of k_wf_mesh: entries are (child reference, f32 entry distance of its box).
 // The first `lds_levels` levels live in LDS (`[level][lane]`, conflict-free 8-B accesses), deeper levels in
-// a private global spill area (`[level][global lane]`, coalesced).  A shallow LDS part keeps 5 waves/SIMD
+// a private global spill area (`[level][global lane]`, coalesced).  A shallow LDS part keeps 4 blocks per CU
 // resident; the spill part is touched by a few percent of the pushes (worst case = BVH4 max_stack).
+// Measured (headline scene): 12 LDS levels 742 ms/step, 8: +5 %, 24: +20 %; 5 waves/SIMD spills and is slower.
 struct MeshStack {
     uint2* lds;        // + threadIdx.x
     uint2* spill;      // + global lane
@@ -514,6 +515,8 @@ struct MeshStack {
     }
 };
 
+template <typename R> constexpr uint32_t kMeshWaveLds = 1024u + 3u * 64u * uint32_t(sizeof(R));  // per wave, see k_wf_mesh
+
 template <typename R, bool STATS>
 __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc, WfPool<R> pool, const uint32_t* __restrict__ mesh_queue,
                                                                  WfCounters* __restrict__ ctr, DeviceCounters* counters,
@@ -522,6 +525,13 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
     extern __shared__ uint2 lds_stack2[];
     MeshStack stk;
     stk.lds = lds_stack2 + threadIdx.x;
+    // wave-private LDS behind the stack: pair table (512 x u16) + one result slot per lane (t, u, v)
+    const uint32_t lane = threadIdx.x & 63u;
+    char* wave_area = reinterpret_cast<char*>(lds_stack2 + size_t(lds_levels) * 256) + (threadIdx.x >> 6) * kMeshWaveLds<R>;
+    uint16_t* pair_tbl = reinterpret_cast<uint16_t*>(wave_area);
+    R* res_t = reinterpret_cast<R*>(wave_area + 1024);
+    R* res_u = res_t + 64;
+    R* res_v = res_u + 64;
     stk.spill = spill + (size_t(blockIdx.x) * blockDim.x + threadIdx.x);
     stk.lds_levels = lds_levels;
     stk.spill_stride = gridDim.x * blockDim.x;
@@ -673,37 +683,83 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
                 }
             }
         }
-        // ---- leaves: every lane that holds one tests its triangles in exact R arithmetic, then pops ----
-        if (STATS) {  // the wave runs the triangle loop as often as its largest leaf needs
-            uint32_t c = (has && node < 0) ? ((uint32_t(~node) & 7u) + 1u) : 0u;
-            for (int off = 32; off > 0; off >>= 1) c = max(c, uint32_t(__shfl_xor(int(c), off)));
-            w_tri += c;
-        }
-        if (has && node < 0) {
-            uint32_t code = uint32_t(~node);
-            uint32_t first = code >> 3, count = (code & 7u) + 1u;
-            for (uint32_t k = 0; k < count; k++) {
-                const TriRec<R>& tr = tris[first + k];
-                if (STATS) cnt.tri_tests++;
-                V3<R> edge1 = ld3(tr.e1), edge2 = ld3(tr.e2);
-                V3<R> ray_x_edge2 = cross(d, edge2);
-                R det = dot(edge1, ray_x_edge2);
-                R dd = hit_back ? fabs(det) : det;
-                if (dd < Lim<R>::eps()) continue;
-                R inv_det = R(1) / det;
-                V3<R> b = o - ld3(tr.v0);
-                R u = dot(b, ray_x_edge2) * inv_det;
-                if (u < R(0) || u > R(1)) continue;
-                V3<R> b_x_edge1 = cross(b, edge1);
-                R v = dot(d, b_x_edge1) * inv_det;
-                if (v < R(0) || u + v > R(1)) continue;
-                R t = dot(edge2, b_x_edge1) * inv_det;
-                if (t <= t_lo || t_max <= t) continue;
-                t_max = t; hit_u = u; hit_v = v; hit_tri = int32_t(mi.tri_base + first + k);
-                found = true;
-                tmax32 = f32_at_least(t_max - t_shift);
+        // ---- leaves: the (lane, triangle) pairs of all lanes that hold a leaf are FLATTENED over the wave, so
+        //      that 64 triangle tests run per pass whatever the leaf sizes are (a per-lane loop ran at 33 % lane
+        //      utilisation: leaves hold 1..4 triangles and a third of the lanes hold none).  Every pass: pair w ->
+        //      (owner lane, k) through a wave-private LDS table, the owner's ray through cross-lane reads, one exact
+        //      test in R, result into LDS; the owners then take their results in k order with the reference's
+        //      interval rule, which makes the outcome identical to the sequential loop (mesh.rs:62-107). ----
+        {
+            const bool leaf = has && node < 0;
+            const uint32_t code = uint32_t(~node);
+            const uint32_t first = leaf ? (code >> 3) : 0u, count = leaf ? ((code & 7u) + 1u) : 0u;
+            uint32_t pre = 0, total = 0;
+#pragma unroll
+            for (int bit = 0; bit < 4; bit++) {
+                unsigned long long m = __ballot(((count >> bit) & 1u) != 0u);
+                pre += lane_prefix(m) << bit;
+                total += uint32_t(__popcll(m)) << bit;
             }
-            pop_next();
+            if (total != 0u) {
+                for (uint32_t j = 0; j < 8u; j++) {
+                    if (__ballot(j < count) == 0ull) break;
+                    if (j < count) pair_tbl[pre + j] = uint16_t(lane | (j << 8));
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t c0 = 0; c0 < total; c0 += 64u) {
+                    if (STATS) w_tri++;
+                    const uint32_t w = c0 + lane;
+                    const bool act = w < total;
+                    const uint32_t e = act ? uint32_t(pair_tbl[w]) : 0u;
+                    const int owner = int(e & 0xFFu);
+                    const uint32_t k = e >> 8;
+                    const V3<R> po = {__shfl(o.x, owner), __shfl(o.y, owner), __shfl(o.z, owner)};
+                    const V3<R> pd = {__shfl(d.x, owner), __shfl(d.y, owner), __shfl(d.z, owner)};
+                    const uint32_t pfirst = uint32_t(__shfl(int(first), owner));
+                    R rt = Lim<R>::inf(), ru = R(0), rv = R(0);  // t = +inf: "no hit" (fails `t_max <= t` at the owner)
+                    if (act) {
+                        const TriRec<R>& tr = tris[pfirst + k];
+                        if (STATS) cnt.tri_tests++;
+                        V3<R> edge1 = ld3(tr.e1), edge2 = ld3(tr.e2);
+                        V3<R> ray_x_edge2 = cross(pd, edge2);
+                        R det = dot(edge1, ray_x_edge2);
+                        R dd = hit_back ? fabs(det) : det;
+                        if (!(dd < Lim<R>::eps())) {
+                            R inv_det = R(1) / det;
+                            V3<R> b = po - ld3(tr.v0);
+                            R u = dot(b, ray_x_edge2) * inv_det;
+                            if (!(u < R(0) || u > R(1))) {
+                                V3<R> b_x_edge1 = cross(b, edge1);
+                                R v = dot(pd, b_x_edge1) * inv_det;
+                                if (!(v < R(0) || u + v > R(1))) {
+                                    rt = dot(edge2, b_x_edge1) * inv_det;
+                                    ru = u;
+                                    rv = v;
+                                }
+                            }
+                        }
+                    }
+                    res_t[lane] = rt; res_u[lane] = ru; res_v[lane] = rv;
+                    __builtin_amdgcn_wave_barrier();
+                    if (leaf) {
+                        const int jlo = max(0, int(c0) - int(pre));
+                        const int jhi = min(int(count), int(c0) + 64 - int(pre));
+                        for (int j = jlo; j < jhi; j++) {
+                            const int idx = int(pre) + j - int(c0);
+                            const R t = res_t[idx];
+                            if (t <= t_lo || t_max <= t) continue;
+                            t_max = t; hit_u = res_u[idx]; hit_v = res_v[idx];
+                            hit_tri = int32_t(mi.tri_base + first + uint32_t(j));
+                            found = true;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (leaf) {
+                    tmax32 = f32_at_least(t_max - t_shift);
+                    pop_next();
+                }
+            }
         }
     }
     if (STATS) {
