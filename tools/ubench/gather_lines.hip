@@ -30,6 +30,27 @@ __global__ void __launch_bounds__(256) k_gather(const float4* __restrict__ table
             uint32_t nxt = DEP ? (__float_as_uint(g.w) ^ (it * 0x9E3779B9u) ^ gtid) : (gtid * 2654435761u + it * 0x9E3779B9u);
             idx = mix32(nxt) % n_lines;
         }
+    } else if (SHAPE == 2) {
+        // every lane fetches its own 64-byte half line (4 x 16 B): a quantised 64-B node
+        uint32_t idx = mix32(gtid * 2654435761u + 12345u) % (n_lines * 2);
+        for (uint32_t it = 0; it < iters; it++) {
+            const float4* p = table + size_t(idx) * 4;
+            float4 a = p[0], b = p[1], c = p[2], d = p[3];
+            acc += a.x + b.y + c.z + d.w;
+            uint32_t nxt = DEP ? (__float_as_uint(d.x) ^ (it * 0x9E3779B9u) ^ gtid) : (gtid * 2654435761u + it * 0x9E3779B9u);
+            idx = mix32(nxt) % (n_lines * 2);
+        }
+    } else if (SHAPE == 3) {
+        // every lane fetches 80 contiguous bytes at a random 80-byte record (5 x 16 B): a TriRec<double>
+        const uint32_t n_rec = uint32_t(size_t(n_lines) * 128 / 80);
+        uint32_t idx = mix32(gtid * 2654435761u + 12345u) % n_rec;
+        for (uint32_t it = 0; it < iters; it++) {
+            const float4* p = table + size_t(idx) * 5;
+            float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+            acc += a.x + b.y + c.z + d.w + e.x;
+            uint32_t nxt = DEP ? (__float_as_uint(e.y) ^ (it * 0x9E3779B9u) ^ gtid) : (gtid * 2654435761u + it * 0x9E3779B9u);
+            idx = mix32(nxt) % n_rec;
+        }
     } else {
         // group of 8 lanes shares one line per instruction; 8 instructions cover the 8 lines of the group's 8 lanes
         const uint32_t part = threadIdx.x & 7u;
@@ -90,6 +111,9 @@ int main() {
             double b = run<0, true>(table, n_lines, bpc, 2000, out);
             double c = run<1, false>(table, n_lines, bpc, 2000, out);
             double d = run<1, true>(table, n_lines, bpc, 2000, out);
+            double e = run<2, true>(table, n_lines, bpc, 2000, out);
+            double f = run<3, true>(table, n_lines, bpc, 2000, out);
+            std::printf("table %5zu MB, %d blocks/CU: 64-B pieces dep %.1f G/s (%.2f TB/s);  80-B records dep %.1f G/s (%.2f TB/s)\n", mb, bpc, e / 1e9, e * 64 / 1e12, f / 1e9, f * 80 / 1e12);
             std::printf("table %5zu MB, %d blocks/CU (%d waves/SIMD): lane-shape indep %.1f G lines/s (%.2f TB/s), dep %.1f (%.2f);  coop-shape indep %.1f (%.2f), dep %.1f (%.2f)\n",
                         mb, bpc, bpc, a / 1e9, a * 128 / 1e12, b / 1e9, b * 128 / 1e12, c / 1e9, c * 128 / 1e12, d / 1e9, d * 128 / 1e12);
             std::fflush(stdout);
