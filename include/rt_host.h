@@ -52,6 +52,11 @@ int rth_tonemap_rgb8(const double* rgba, uint32_t w, uint32_t h, uint8_t* rgb_ou
 /* The same followed by an 8-bit RGB PNG file (zlib deflate). */
 int rth_save_png(const char* path, const double* rgba, uint32_t w, uint32_t h);
 
+/* Buffer::from_image (src/buffer.rs:30-48): decodes a PNG or baseline-JPEG file into w*h RGB f32
+ * triples (8-bit: x/255, 16-bit: x/65535), row 0 first.  The caller frees with rth_free_image. */
+int rth_load_image(const char* path, float** rgb_out, uint32_t* w_out, uint32_t* h_out);
+void rth_free_image(float* rgb);
+
 const char* rth_last_error(void);
 
 #ifdef __cplusplus

@@ -118,8 +118,8 @@ typedef enum RtTextureType {
     RT_TEX_CHECKER = 3,        /* texture/checkerboard.rs:34  a = even, b = odd, scale */
     RT_TEX_CHECKER_SOLID = 4,  /* texture/checkerboard.rs:74                           */
     RT_TEX_LERP = 5,           /* texture/interpolate.rs  a, b, c = t                  */
-    RT_TEX_IMAGE = 6,          /* texture/image.rs   (not supported by the kernels yet) */
-    RT_TEX_NOISE_SOLID = 7,    /* texture/noise.rs   (not supported by the kernels yet) */
+    RT_TEX_IMAGE = 6,          /* texture/image.rs:37-53  texels, width, height (repeat, nearest) */
+    RT_TEX_NOISE_SOLID = 7,    /* texture/noise.rs:33-38  v = scale vector, samples, perlin_* tables */
     RT_TEX_CHANNEL = 8,        /* texture/channel.rs  a = colour texture, channel      */
     RT_TEX_UV_DEBUG = 9        /* texture/uv_debug.rs                                  */
 } RtTextureType;
@@ -128,9 +128,17 @@ typedef struct RtTexture {
     uint32_t type;
     int32_t  a, b, c;
     uint32_t channel;
-    uint32_t _pad;
-    double   v[3];
+    uint32_t samples;           /* NOISE_SOLID: turbulence octaves (noise.rs:27, default 7)            */
+    double   v[3];              /* CONST_*: the value; NOISE_SOLID: NoiseSolidTexture::scale (noise.rs:16) */
     double   scale;
+    /* IMAGE: what Buffer::from_image keeps (buffer.rs:30-48): width*height RGB triples as decoded by
+     * `into_rgb32f` (8-bit: x/255, 16-bit: x/65535, in f32), row 0 = top row of the file.            */
+    const float* texels;
+    uint32_t width, height;
+    /* NOISE_SOLID: the generator's tables (noise/perlin.rs:13-18). The reference fills them from its
+     * entropy-seeded RNG (perlin.rs:21-36); the caller passes its own.                                */
+    const double*   perlin_vec;   /* 256 unit vectors, x y z            */
+    const uint32_t* perlin_perm;  /* perm_x[256], perm_y[256], perm_z[256], values 0..255 */
 } RtTexture;
 
 typedef struct RtSceneDesc {

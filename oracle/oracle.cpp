@@ -275,6 +275,67 @@ struct Channel : Sampler<double> {  // channel.rs:22-25
     uint32_t channel;
     double sample(double u, double v, const Vec4& p) const override { return color->sample(u, v, p)[int(channel)]; }
 };
+inline size_t f64_as_usize(double x) {  // Rust `as usize`: saturating, NaN -> 0
+    if (!(x > 0.0)) return 0;
+    if (x >= 18446744073709551615.0) return SIZE_MAX;
+    return size_t(x);
+}
+struct ImageTexture : Sampler<Vec4> {  // image.rs:37-53 (TextureRepeat::Repeat, nearest neighbour)
+    const float* texels = nullptr;     // Buffer::from_image (buffer.rs:30-48): f32 rgb widened to f64
+    uint32_t width = 0, height = 0;
+    Vec4 sample(double u, double v, const Vec4&) const override {
+        u = u - std::floor(u);
+        v = v - std::floor(v);
+        double w = double(width) - 0.001, h = double(height) - 0.001;
+        size_t x = f64_as_usize(u * w), y = f64_as_usize(v * h);
+        const float* t = texels + (y * size_t(width) + x) * 3;  // Buffer::get_pixel (buffer.rs:54-56)
+        return vec(double(t[0]), double(t[1]), double(t[2]));
+    }
+};
+struct PerlinNoise3D {  // noise/perlin.rs
+    const double* random_vec = nullptr;  // 256 x (x, y, z)
+    const uint32_t* perm = nullptr;      // perm_x, perm_y, perm_z
+    static double smooth(double x) { return x * x * (3.0 - 2.0 * x); }
+    double sample(const Vec4& p) const {  // perlin.rs:81-101 + trilinear_interpolation :57-77
+        double u = p[0] - std::floor(p[0]), v = p[1] - std::floor(p[1]), w = p[2] - std::floor(p[2]);
+        int32_t i = f64_as_i32(std::floor(p[0])), j = f64_as_i32(std::floor(p[1])), k = f64_as_i32(std::floor(p[2]));
+        double uu = smooth(u), vv = smooth(v), ww = smooth(w);
+        double acc = 0.0;
+        for (int di = 0; di < 2; di++)
+            for (int dj = 0; dj < 2; dj++)
+                for (int dk = 0; dk < 2; dk++) {
+                    uint32_t idx = perm[uint32_t(int32_t(uint32_t(di) + uint32_t(i))) & 255u] ^
+                                   perm[256 + (uint32_t(int32_t(uint32_t(dj) + uint32_t(j))) & 255u)] ^
+                                   perm[512 + (uint32_t(int32_t(uint32_t(dk) + uint32_t(k))) & 255u)];
+                    Vec4 c = vec(random_vec[3 * idx], random_vec[3 * idx + 1], random_vec[3 * idx + 2]);
+                    double fi = double(di), fj = double(dj), fk = double(dk);
+                    Vec4 v_weight = vec(u - fi, v - fj, w - fk);
+                    acc += (fi * uu + (1.0 - fi) * (1.0 - uu)) * (fj * vv + (1.0 - fj) * (1.0 - vv)) *
+                           (fk * ww + (1.0 - fk) * (1.0 - ww)) * dot(c, v_weight);
+                }
+        return acc;
+    }
+    double sample_turbulence(const Vec4& p0, size_t samples) const {  // perlin.rs:103-113
+        double acc = 0.0, weight = 1.0;
+        Vec4 p = p0;
+        for (size_t s = 0; s < samples; s++) {
+            acc += weight * sample(p);
+            weight *= 0.5;
+            p = p * 2.0;
+        }
+        return std::fabs(acc);
+    }
+};
+struct NoiseSolidTexture : Sampler<double> {  // noise.rs:10-38
+    PerlinNoise3D noise;
+    Vec4 scale = vec(1.0, 1.0, 1.0);
+    size_t samples = 7;
+    double sample(double, double, const Vec4& p) const override {
+        Vec4 p_scaled = p * scale;
+        double sampled = noise.sample_turbulence(p_scaled, samples);
+        return 0.5 * (1.0 + det_sin(p_scaled.z() + 10.0 * sampled));  // noise.rs:28 (f64::sin -> det_sin)
+    }
+};
 struct UvDebugTexture : Sampler<Vec4> {  // uv_debug.rs:11-13
     Vec4 sample(double u, double v, const Vec4&) const override { return vec(u, v, 0.5); }
 };
@@ -1010,8 +1071,22 @@ struct Builder {
                 auto c = std::make_shared<Channel>(); c->color = w.color_tex[t.a]; c->channel = t.channel; w.float_tex[i] = c; tex_state[i] = 2;
                 return true;
             }
+            case RT_TEX_IMAGE: {
+                if (!t.texels || t.width == 0 || t.height == 0) { g_err = "image texture without texels"; return false; }
+                auto c = std::make_shared<ImageTexture>(); c->texels = t.texels; c->width = t.width; c->height = t.height;
+                w.color_tex[i] = c; tex_state[i] = 1;
+                return true;
+            }
+            case RT_TEX_NOISE_SOLID: {
+                if (!t.perlin_vec || !t.perlin_perm) { g_err = "noise texture without generator tables"; return false; }
+                auto c = std::make_shared<NoiseSolidTexture>();
+                c->noise.random_vec = t.perlin_vec; c->noise.perm = t.perlin_perm;
+                c->scale = vec(t.v[0], t.v[1], t.v[2]); c->samples = t.samples;
+                w.float_tex[i] = c; tex_state[i] = 2;
+                return true;
+            }
             default:
-                g_err = "oracle: texture type not restated (image / noise)";
+                g_err = "oracle: unknown texture type";
                 return false;
         }
     }

@@ -55,8 +55,10 @@ class RtMaterial(C.Structure):
 
 class RtTexture(C.Structure):
     _fields_ = [("type", C.c_uint32), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_int32),
-                ("channel", C.c_uint32), ("_pad", C.c_uint32), ("v", C.c_double * 3),
-                ("scale", C.c_double)]
+                ("channel", C.c_uint32), ("samples", C.c_uint32), ("v", C.c_double * 3),
+                ("scale", C.c_double),
+                ("texels", C.POINTER(C.c_float)), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("perlin_vec", C.POINTER(C.c_double)), ("perlin_perm", C.POINTER(C.c_uint32))]
 
 
 class RtSceneDesc(C.Structure):
@@ -157,6 +159,10 @@ def load_host_lib() -> C.CDLL:
         lib.rth_tonemap_rgb8.restype = C.c_int
         lib.rth_save_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
         lib.rth_save_png.restype = C.c_int
+        lib.rth_load_image.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        lib.rth_load_image.restype = C.c_int
+        lib.rth_free_image.argtypes = [C.POINTER(C.c_float)]
+        lib.rth_free_image.restype = None
         lib.rth_last_error.argtypes = []
         lib.rth_last_error.restype = C.c_char_p
         _host_lib = lib
@@ -268,6 +274,20 @@ def save_png(path: str, rgba: np.ndarray) -> None:
     st = lib.rth_save_png(path.encode(), rgba.ctypes.data, w, h)
     if st != RT_OK:
         raise RtError(st, lib.rth_last_error().decode())
+
+
+def load_image(path: str) -> np.ndarray:
+    """Buffer::from_image (buffer.rs:30-48): PNG / baseline JPEG -> (h, w, 3) float32."""
+    lib = load_host_lib()
+    ptr = C.POINTER(C.c_float)()
+    w, h = C.c_uint32(), C.c_uint32()
+    st = lib.rth_load_image(path.encode(), C.byref(ptr), C.byref(w), C.byref(h))
+    if st != RT_OK:
+        raise RtError(st, lib.rth_last_error().decode())
+    try:
+        return np.ctypeslib.as_array(ptr, shape=(h.value, w.value, 3)).copy()
+    finally:
+        lib.rth_free_image(ptr)
 
 
 class DeviceScene:

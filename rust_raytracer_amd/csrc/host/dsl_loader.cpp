@@ -7,9 +7,8 @@
 // `$label` references resolved per entity kind with later labels overwriting earlier
 // ones (:108-125), inline `( ... )` declarations (:292-452), warnings printed for bad
 // lines (:93-96,127-135), "No world/lights object" (:153-155).
-// Not available here: `image` (needs PNG/JPEG decoding), `noise_solid`/`perlin` — they
-// report an error for that line exactly like any other failing declaration, so a scene
-// using them loads without the affected labels.
+// `image` decodes PNG / baseline JPEG itself (image_loader.cpp); `perlin` fills its tables from the
+// scene RNG (the reference: entropy-seeded, perlin.rs:21-36).
 #include <cstdio>
 #include <fstream>
 #include <map>
@@ -31,7 +30,7 @@ struct Loader {
     SceneRng& rng;
     std::string asset_path;
     std::string* log;
-    std::map<std::string, int> objects, materials, color_tex, float_tex;
+    std::map<std::string, int> objects, materials, color_tex, float_tex, noises;
     SceneConfig scene_config = default_scene_config();
 
     using Params = std::vector<std::string>;
@@ -158,10 +157,26 @@ struct Loader {
         }
         if (type == "uv_debug") { *out = {Kind::TexColor, b.tex_uv_debug()}; return true; }
         if (type == "noise") { *err = "ParseError: Not implemented"; return false; }  // scene.rs:257
-        if (type == "image" || type == "noise_solid" || type == "perlin") {
-            *err = "ParseError: '" + type + "' is not available in this build (no image decoder / noise yet)";
-            return false;
+        if (type == "image") {  // scene.rs:542-553
+            if (!next(&a)) { *err = "ParseError: Image texture missing parameters"; return false; }
+            std::vector<float> rgb;
+            uint32_t w = 0, h = 0;
+            if (!load_image_rgb32f(asset_path + a, &rgb, &w, &h, err)) return false;
+            *out = {Kind::TexColor, b.tex_image(std::move(rgb), w, h)};
+            return true;
         }
+        if (type == "noise_solid") {  // scene.rs:555-570
+            if (!next(&a)) { *err = "ParseError: Noise texture missing parameters"; return false; }
+            int gen;
+            if (!get_entity(a, Kind::Noise, noises, "noise gen", &gen, err)) return false;
+            double scale = 1.0;
+            size_t samples = 7;
+            if (next(&bb) && !parse_f64(bb, &scale)) { *err = "invalid float literal"; return false; }
+            if (next(&c) && !parse_usize(c, &samples)) { *err = "invalid digit found in string"; return false; }
+            *out = {Kind::TexFloat, b.tex_noise_solid(gen, scale, uint32_t(samples))};
+            return true;
+        }
+        if (type == "perlin") { *out = {Kind::Noise, b.noise_perlin(rng)}; return true; }  // scene.rs:282
 
         // ---- materials ----
         if (type == "lambertian") {
@@ -401,7 +416,7 @@ bool load_dsl_scene(const std::string& file_path, const std::string& asset_path,
         *err = "No such file or directory: " + file_path;  // main.rs:43 `File::open(file_path)?`
         return false;
     }
-    Loader L{out->builder, rng, asset_path, log, {}, {}, {}, {}, default_scene_config()};
+    Loader L{out->builder, rng, asset_path, log, {}, {}, {}, {}, {}, default_scene_config()};
     std::string line;
     size_t line_number = 0;
     for (; std::getline(in, line); line_number++) {
@@ -436,7 +451,7 @@ bool load_dsl_scene(const std::string& file_path, const std::string& asset_path,
             case Kind::Material: L.materials[label] = ent.id; break;
             case Kind::TexColor: L.color_tex[label] = ent.id; break;
             case Kind::TexFloat: L.float_tex[label] = ent.id; break;
-            case Kind::Noise: break;
+            case Kind::Noise: L.noises[label] = ent.id; break;
         }
     }
     auto w = L.objects.find("world"), l = L.objects.find("lights");

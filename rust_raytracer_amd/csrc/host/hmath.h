@@ -91,6 +91,11 @@ struct SceneRng {
     double uniform() { return double(next() >> 11) * (1.0 / 9007199254740992.0); }
     double range(double lo, double hi) { return lo + (hi - lo) * uniform(); }
     uint32_t below(uint32_t n) { return uint32_t(((next() >> 32) * uint64_t(n)) >> 32); }
+    // StandardNormal stand-in: Box-Muller, cosine branch, two uniforms (as the render RNG, rt_device.h)
+    double normal() {
+        double u1 = uniform(), u2 = uniform();
+        return std::sqrt(-2.0 * std::log(1.0 - u1)) * std::cos(6.283185307179586476925286766559 * u2);
+    }
 };
 
 }  // namespace rth

@@ -1,4 +1,5 @@
 // extern "C" entry points of librt_host.so (include/rt_host.h).
+#include <cstdlib>
 #include <cstring>
 
 #include "host_internal.h"
@@ -107,5 +108,18 @@ int rth_save_png(const char* path, const double* rgba, uint32_t w, uint32_t h) {
     if (!rth::write_png_rgb8(path, rgb.data(), w, h, &err)) return fail(err);
     return RT_OK;
 }
+
+int rth_load_image(const char* path, float** rgb_out, uint32_t* w_out, uint32_t* h_out) {
+    if (!path || !rgb_out || !w_out || !h_out) return fail("rth_load_image: NULL argument");
+    std::vector<float> rgb;
+    std::string err;
+    if (!rth::load_image_rgb32f(path, &rgb, w_out, h_out, &err)) return fail(err);
+    float* p = static_cast<float*>(std::malloc(rgb.size() * sizeof(float)));
+    if (!p) return fail("rth_load_image: out of memory");
+    std::memcpy(p, rgb.data(), rgb.size() * sizeof(float));
+    *rgb_out = p;
+    return RT_OK;
+}
+void rth_free_image(float* rgb) { std::free(rgb); }
 
 }  // extern "C"

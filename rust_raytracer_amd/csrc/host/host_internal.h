@@ -44,6 +44,9 @@ bool split_key_value(const std::string& s, std::string* key, std::string* value)
 
 void make_camera(const SceneConfig& sc, RtCameraDesc* out);  // camera.rs:47-130
 
+// texture/image.rs + buffer.rs:30-48 (PNG, baseline JPEG -> RGB f32)
+bool load_image_rgb32f(const std::string& path, std::vector<float>* rgb, uint32_t* width, uint32_t* height, std::string* err);
+
 std::unique_ptr<MeshData> load_obj(const std::string& path, std::string* log, std::string* err);
 
 struct LoadedScene {

@@ -108,6 +108,40 @@ int SceneBuilder::tex_uv_debug() {
     textures_.push_back(t);
     return int(textures_.size()) - 1;
 }
+int SceneBuilder::tex_image(std::vector<float> rgb, uint32_t width, uint32_t height) {
+    images_.push_back(std::make_unique<std::vector<float>>(std::move(rgb)));
+    RtTexture t{}; t.type = RT_TEX_IMAGE; t.a = t.b = t.c = -1; t.scale = 1.0;
+    t.texels = images_.back()->data(); t.width = width; t.height = height;
+    textures_.push_back(t);
+    return int(textures_.size()) - 1;
+}
+// PerlinNoise3D::new (perlin.rs:21-36): 256 random unit vectors, then three Fisher-Yates permutations
+// (perlin.rs:50-55: for i in (1..256).rev() { swap(i, gen_range(0..=i)) }).  Same draw order, our RNG.
+int SceneBuilder::noise_perlin(SceneRng& rng) {
+    auto p = std::make_unique<Perlin>();
+    p->vec.resize(256 * 3);
+    for (int i = 0; i < 256; i++) {
+        double x = rng.normal(), y = rng.normal(), z = rng.normal();  // Vec4::random_unit (vec4.rs:42-48)
+        double len = std::sqrt(x * x + y * y + z * z);
+        p->vec[3 * i + 0] = x / len; p->vec[3 * i + 1] = y / len; p->vec[3 * i + 2] = z / len;
+    }
+    p->perm.resize(3 * 256);
+    for (int a = 0; a < 3; a++) {
+        uint32_t* q = p->perm.data() + 256 * a;
+        for (uint32_t i = 0; i < 256; i++) q[i] = i;
+        for (uint32_t i = 255; i >= 1; i--) std::swap(q[i], q[rng.below(i + 1)]);
+    }
+    perlins_.push_back(std::move(p));
+    return int(perlins_.size()) - 1;
+}
+int SceneBuilder::tex_noise_solid(int generator, double scale, uint32_t samples) {
+    const Perlin& g = *perlins_[size_t(generator)];
+    RtTexture t{}; t.type = RT_TEX_NOISE_SOLID; t.a = t.b = t.c = -1; t.scale = 1.0;
+    t.v[0] = t.v[1] = t.v[2] = scale; t.samples = samples;
+    t.perlin_vec = g.vec.data(); t.perlin_perm = g.perm.data();
+    textures_.push_back(t);
+    return int(textures_.size()) - 1;
+}
 bool SceneBuilder::tex_is_color(int tex) const {
     const RtTexture& t = textures_[tex];
     switch (t.type) {

@@ -27,6 +27,9 @@ public:
     int tex_lerp(int a, int b, int t);
     int tex_channel(int color, uint32_t channel);
     int tex_uv_debug();
+    int tex_image(std::vector<float> rgb, uint32_t width, uint32_t height);  // image.rs:29-35
+    int noise_perlin(SceneRng& rng);                                         // perlin.rs:21-36 (returns a generator id)
+    int tex_noise_solid(int generator, double scale, uint32_t samples);      // scene.rs:555-565
     bool tex_is_color(int tex) const;
 
     // --- materials (src/material/*.rs) ---
@@ -74,6 +77,9 @@ private:
     std::vector<RtMesh> meshes_;
     std::vector<RtMaterial> materials_;
     std::vector<RtTexture> textures_;
+    std::vector<std::unique_ptr<std::vector<float>>> images_;
+    struct Perlin { std::vector<double> vec; std::vector<uint32_t> perm; };
+    std::vector<std::unique_ptr<Perlin>> perlins_;
     RtSceneDesc desc_{};
 };
 

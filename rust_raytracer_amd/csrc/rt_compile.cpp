@@ -279,66 +279,166 @@ struct Compiler {
         }
     }
 
-    bool texture_ok(int32_t t, int depth, bool* needs_uv) {
-        if (t < 0 || uint32_t(t) >= d.n_textures) return fail(RT_E_INVALID, "texture index out of range");
-        if (depth > 64) return fail(RT_E_INVALID, "texture graph too deep (cycle?)");
+    // ---- texture expressions -> postfix programs ----
+    std::map<const void*, uint32_t> image_base, perlin_index;
+    std::map<int32_t, int32_t> program_of;  // texture id -> packed program id
+
+    // Emits the program of texture `t`; returns its kind (1 colour, 2 float) or 0 on error.
+    // `live` = values already on the stack when this sub-expression starts.
+    int emit_texture(int32_t t, int depth, int live, int* max_live, bool* needs_uv) {
+        if (t < 0 || uint32_t(t) >= d.n_textures) { fail(RT_E_INVALID, "texture index out of range"); return 0; }
+        if (depth > 64) { fail(RT_E_INVALID, "texture graph too deep (cycle?)"); return 0; }
         const RtTexture& tx = d.textures[t];
+        TextureRec<double> r{};
+        r.type = int32_t(tx.type);
+        r.v[0] = tx.v[0]; r.v[1] = tx.v[1]; r.v[2] = tx.v[2];
+        r.scale = tx.scale;
+        int kind = 0;
         switch (tx.type) {
-            case RT_TEX_CONST_COLOR:
-            case RT_TEX_CONST_FLOAT:
-                return true;
-            case RT_TEX_UV_DEBUG:
+            case RT_TEX_CONST_COLOR: kind = 1; break;
+            case RT_TEX_CONST_FLOAT: kind = 2; break;
+            case RT_TEX_UV_DEBUG: kind = 1; *needs_uv = true; break;
+            case RT_TEX_IMAGE: {
+                kind = 1;
+                out.needs_tex_interpreter = true;
                 *needs_uv = true;
-                return true;
+                if (!tx.texels || tx.width == 0 || tx.height == 0) { fail(RT_E_INVALID, "image texture without texels"); return 0; }
+                auto it = image_base.find(tx.texels);
+                if (it == image_base.end()) {
+                    size_t n = size_t(tx.width) * tx.height * 3;
+                    if ((out.texels.size() + n) / 3 > 0xFFFFFFFFull) { fail(RT_E_UNSUPPORTED, "image textures too large"); return 0; }
+                    uint32_t base = uint32_t(out.texels.size() / 3);
+                    out.texels.insert(out.texels.end(), tx.texels, tx.texels + n);
+                    it = image_base.emplace(tx.texels, base).first;
+                }
+                r.data = it->second;
+                r.width = tx.width;
+                r.height = tx.height;
+                break;
+            }
+            case RT_TEX_NOISE_SOLID: {
+                kind = 2;
+                out.needs_tex_interpreter = true;
+                if (!tx.perlin_vec || !tx.perlin_perm) { fail(RT_E_INVALID, "noise texture without generator tables"); return 0; }
+                auto it = perlin_index.find(tx.perlin_vec);
+                if (it == perlin_index.end()) {
+                    uint32_t idx = uint32_t(out.perlin_vec.size() / 768);
+                    out.perlin_vec.insert(out.perlin_vec.end(), tx.perlin_vec, tx.perlin_vec + 768);
+                    for (int k = 0; k < 768; k++) out.perlin_perm.push_back(tx.perlin_perm[k] & 255u);
+                    it = perlin_index.emplace(tx.perlin_vec, idx).first;
+                }
+                r.data = it->second;
+                r.aux = int32_t(tx.samples);
+                break;
+            }
             case RT_TEX_CHECKER:
-                *needs_uv = true;
-                return texture_ok(tx.a, depth + 1, needs_uv) && texture_ok(tx.b, depth + 1, needs_uv);
-            case RT_TEX_CHECKER_SOLID:
-                return texture_ok(tx.a, depth + 1, needs_uv) && texture_ok(tx.b, depth + 1, needs_uv);
+            case RT_TEX_CHECKER_SOLID: {
+                if (tx.type == RT_TEX_CHECKER) *needs_uv = true;
+                int ka = emit_texture(tx.a, depth + 1, live, max_live, needs_uv);
+                if (!ka) return 0;
+                r.aux = int32_t(out.textures.size()) - 1;  // root op of the even input (eval_texture_simple)
+                int kb = emit_texture(tx.b, depth + 1, live + 1, max_live, needs_uv);
+                if (!kb) return 0;
+                r.data = uint32_t(out.textures.size()) - 1u;  // root op of the odd input
+                if (ka != kb) { fail(RT_E_INVALID, "checker inputs differ in type"); return 0; }
+                kind = ka;
+                break;
+            }
+            case RT_TEX_LERP: {
+                out.needs_tex_interpreter = true;
+                int ka = emit_texture(tx.a, depth + 1, live, max_live, needs_uv);
+                if (!ka) return 0;
+                int kb = emit_texture(tx.b, depth + 1, live + 1, max_live, needs_uv);
+                if (!kb) return 0;
+                int kc = emit_texture(tx.c, depth + 1, live + 2, max_live, needs_uv);
+                if (!kc) return 0;
+                if (ka != kb || kc != 2) { fail(RT_E_INVALID, "lerp inputs have wrong types"); return 0; }
+                kind = ka;
+                break;
+            }
+            case RT_TEX_CHANNEL: {
+                out.needs_tex_interpreter = true;
+                int ka = emit_texture(tx.a, depth + 1, live, max_live, needs_uv);
+                if (!ka) return 0;
+                if (ka != 1) { fail(RT_E_INVALID, "channel input must be a colour texture"); return 0; }
+                if (tx.channel > 3) { fail(RT_E_INVALID, "channel index out of range"); return 0; }
+                r.aux = int32_t(tx.channel);
+                kind = 2;
+                break;
+            }
             default:
-                return fail(RT_E_UNSUPPORTED, "texture type not supported by the HIP kernels yet (lerp/image/noise/channel)");
+                fail(RT_E_INVALID, "unknown texture type");
+                return 0;
         }
+        if (live + 1 > *max_live) *max_live = live + 1;
+        out.textures.push_back(r);
+        return kind;
     }
 
-    bool compile_tables() {
-        out.textures.resize(d.n_textures);
-        for (uint32_t i = 0; i < d.n_textures; i++) {
-            const RtTexture& t = d.textures[i];
-            TextureRec<double> r{};
-            r.type = int32_t(t.type);
-            r.a = t.a; r.b = t.b; r.c = t.c;
-            r.v[0] = t.v[0]; r.v[1] = t.v[1]; r.v[2] = t.v[2];
-            r.scale = t.scale;
-            out.textures[i] = r;
+    // Compiles (once) the program of the texture in a material slot; `want` = 1 colour, 2 float.
+    bool texture_program(int32_t t, int want, int32_t* packed, bool* needs_uv) {
+        auto it = program_of.find(t);
+        if (it == program_of.end()) {
+            size_t first = out.textures.size();
+            int max_live = 0;
+            bool uv = false;
+            int kind = emit_texture(t, 0, 0, &max_live, &uv);
+            if (!kind) return false;
+            size_t count = out.textures.size() - first;
+            if (max_live > kTexStackDepth)
+                return fail(RT_E_UNSUPPORTED, "texture expression needs more than 4 live values (nest the deeper input first)");
+            if (first >= (1u << kTexProgShift) || count >= (1u << 11)) return fail(RT_E_UNSUPPORTED, "texture programs too large");
+            // kind and uv use are kept in the two top bits of the map entry's companion tables
+            program_kind[t] = kind;
+            program_uv[t] = uv;
+            it = program_of.emplace(t, int32_t(first | (count << kTexProgShift))).first;
         }
+        if (program_kind[t] != want) return fail(RT_E_INVALID, want == 1 ? "expected a colour texture" : "expected a float texture");
+        if (program_uv[t]) *needs_uv = true;
+        *packed = it->second;
+        return true;
+    }
+    std::map<int32_t, int> program_kind;
+    std::map<int32_t, bool> program_uv;
+
+    bool compile_tables() {
         out.materials.resize(d.n_materials);
         out.material_params.resize(d.n_materials);
         for (uint32_t i = 0; i < d.n_materials; i++) {
             const RtMaterial& m = d.materials[i];
             MaterialRec r{};
             r.type = int32_t(m.type);
-            r.tex_a = m.tex_a; r.tex_b = m.tex_b; r.tex_c = m.tex_c;
+            r.tex_a = r.tex_b = r.tex_c = -1;
             bool needs_uv = false;
             switch (m.type) {
                 case RT_MAT_LAMBERTIAN: case RT_MAT_EMISSIVE: case RT_MAT_ISOTROPIC:
-                    if (!texture_ok(m.tex_a, 0, &needs_uv)) return false;
+                    if (!texture_program(m.tex_a, 1, &r.tex_a, &needs_uv)) return false;
                     break;
                 case RT_MAT_METAL:
-                    if (!texture_ok(m.tex_a, 0, &needs_uv) || !texture_ok(m.tex_b, 0, &needs_uv)) return false;
+                    if (!texture_program(m.tex_a, 1, &r.tex_a, &needs_uv) || !texture_program(m.tex_b, 2, &r.tex_b, &needs_uv)) return false;
                     break;
                 case RT_MAT_GLOSSY:
-                    if (!texture_ok(m.tex_a, 0, &needs_uv) || !texture_ok(m.tex_b, 0, &needs_uv)) return false;
-                    if (m.tex_c >= 0) return fail(RT_E_UNSUPPORTED, "normal-mapped glossy is not supported by the HIP kernels yet");
+                    if (!texture_program(m.tex_a, 1, &r.tex_a, &needs_uv) || !texture_program(m.tex_b, 2, &r.tex_b, &needs_uv)) return false;
+                    if (m.tex_c >= 0) {
+                        if (!texture_program(m.tex_c, 1, &r.tex_c, &needs_uv)) return false;
+                        r.has_normal_map = 1;
+                        out.needs_tex_interpreter = true;
+                    }
                     break;
                 case RT_MAT_DIELECTRIC:
                     break;
                 case RT_MAT_NORMAL_DEBUG:
-                    if (m.tex_c >= 0) return fail(RT_E_UNSUPPORTED, "normal-mapped normal_debug is not supported by the HIP kernels yet");
+                    if (m.tex_c >= 0) {
+                        if (!texture_program(m.tex_c, 1, &r.tex_c, &needs_uv)) return false;
+                        r.has_normal_map = 1;
+                        out.needs_tex_interpreter = true;
+                    }
                     break;
                 default:
                     return fail(RT_E_INVALID, "unknown material type");
             }
-            r.needs_uv = needs_uv ? 1 : 0;
+            // a normal map needs the tangent frame, which the sphere only computes together with (u, v) (sphere.rs:78-88)
+            r.needs_uv = (needs_uv || r.has_normal_map) ? 1 : 0;
             out.materials[i] = r;
             out.material_params[i].ior = m.ior;
             out.material_params[i].inv_ior = 1.0 / m.ior;  // glossy.rs:30

@@ -27,8 +27,12 @@ struct CompiledScene {
     std::vector<TriAttr<double>> attrs;      // same order
     std::vector<MaterialRec> materials;
     std::vector<MaterialParams<double>> material_params;
-    std::vector<TextureRec<double>> textures;
+    std::vector<TextureRec<double>> textures;  // postfix ops of every texture program (see rt_scene.h)
+    std::vector<float> texels;                 // image textures, concatenated
+    std::vector<double> perlin_vec;            // noise generators, 768 doubles each
+    std::vector<uint32_t> perlin_perm;         // 768 each
     std::vector<LightRec> lights;
+    bool needs_tex_interpreter = false;        // any lerp / image / noise / channel op or normal map
     int32_t lights_is_list = 0;
     uint32_t max_bvh_depth = 1;
 };

@@ -431,20 +431,171 @@ RT_DEV SceneView<R> scene_tables_to_lds(const SceneView<R>& g, char* lds) {
 }
 
 // ------------------------------------------------------------------ HitRecord (object.rs:32-72)
+// ------------------------------------------------------------------ textures (texture/*.rs)
+template <typename R> RT_DEV uint32_t as_u32_sat(R x) {  // Rust `as u32`
+    if (!(x > R(0))) return 0u;
+    if (x >= R(4294967295.0)) return 4294967295u;
+    return uint32_t(x);
+}
+template <typename R> RT_DEV int32_t as_i32_sat(R x) {
+    if (x != x) return 0;
+    if (x <= R(-2147483648.0)) return INT32_MIN;
+    if (x >= R(2147483647.0)) return INT32_MAX;
+    return int32_t(x);
+}
+RT_DEV double sin_r(double x) { return det_sin(x); }
+RT_DEV float sin_r(float x) { return sinf(x); }
+
+// noise/perlin.rs:81-101 (sample) + :57-77 (trilinear_interpolation), arithmetic in the reference's order
+template <typename R> RT_DEV R perlin_sample(const SceneView<R>& sc, uint32_t gen, V3<R> p) {
+    const R u = p.x - floor(p.x), v = p.y - floor(p.y), w = p.z - floor(p.z);
+    const uint32_t i = uint32_t(as_i32_sat(floor(p.x))), j = uint32_t(as_i32_sat(floor(p.y))), k = uint32_t(as_i32_sat(floor(p.z)));
+    const R uu = u * u * (R(3) - R(2) * u), vv = v * v * (R(3) - R(2) * v), ww = w * w * (R(3) - R(2) * w);
+    const uint32_t* perm = sc.perlin_perm + size_t(gen) * 768;
+    const R* vec = sc.perlin_vec + size_t(gen) * 768;
+    R acc = R(0);
+    // one corner per trip, NOT unrolled: eight unrolled corners hoist 48 loads and push the whole shade kernel
+    // to 256 VGPRs; noise textures are rare and the order of the additions is the reference's either way
+#pragma clang loop unroll(disable)
+    for (uint32_t corner = 0; corner < 8; corner++) {
+        const uint32_t di = corner >> 2, dj = (corner >> 1) & 1u, dk = corner & 1u;
+        uint32_t idx = perm[(di + i) & 255u] ^ perm[256u + ((dj + j) & 255u)] ^ perm[512u + ((dk + k) & 255u)];
+        V3<R> c = mk<R>(vec[3 * idx], vec[3 * idx + 1], vec[3 * idx + 2]);
+        R fi = R(di), fj = R(dj), fk = R(dk);
+        V3<R> v_weight = mk<R>(u - fi, v - fj, w - fk);
+        acc += (fi * uu + (R(1) - fi) * (R(1) - uu)) * (fj * vv + (R(1) - fj) * (R(1) - vv)) *
+               (fk * ww + (R(1) - fk) * (R(1) - ww)) * dot(c, v_weight);
+    }
+    return acc;
+}
+// noise/perlin.rs:103-113 + texture/noise.rs:28-37
+template <typename R> RT_DEV R noise_solid_sample(const SceneView<R>& sc, const TextureRec<R>& tx, V3<R> p) {
+    V3<R> q = mk<R>(p.x * tx.v[0], p.y * tx.v[1], p.z * tx.v[2]);
+    const R qz = q.z;
+    R acc = R(0), weight = R(1);
+#pragma clang loop unroll(disable)
+    for (int32_t s = 0; s < tx.aux; s++) {
+        acc += weight * perlin_sample(sc, tx.data, q);
+        weight *= R(0.5);
+        q = q * R(2);
+    }
+    return R(0.5) * (R(1) + sin_r(qz + R(10) * fabs(acc)));
+}
+// texture/image.rs:37-53: repeat, nearest neighbour; texels are the f32 values of Buffer::from_image
+template <typename R> RT_DEV V3<R> image_sample(const SceneView<R>& sc, const TextureRec<R>& tx, R u, R v) {
+    u = u - floor(u);
+    v = v - floor(v);
+    R w = R(tx.width) - R(0.001), h = R(tx.height) - R(0.001);
+    uint32_t x = as_u32_sat(u * w), y = as_u32_sat(v * h);
+    if (x >= tx.width) x = tx.width - 1;  // unreachable in f64 (u < 1); guards the f32 kernels
+    if (y >= tx.height) y = tx.height - 1;
+    const float* t = sc.texels + (size_t(tx.data) + size_t(y) * tx.width + x) * 3;
+    return mk<R>(R(t[0]), R(t[1]), R(t[2]));
+}
+
+// Programs made of constants, uv_debug and checkers only (the common case) need no value stack: walk from the
+// root (the program's last op) down the checker's chosen input to a leaf.  CHECKER ops carry the op indices of
+// their inputs' roots for this (aux = even, data = odd).
+template <typename R> RT_DEV V3<R> eval_texture_simple(const SceneView<R>& sc, int32_t prog, R u, R v, V3<R> p) {
+    int32_t t = (prog & ((1 << kTexProgShift) - 1)) + (prog >> kTexProgShift) - 1;
+    for (;;) {
+        const TextureRec<R>& tx = sc.textures[t];
+        if (tx.type == RT_TEX_CHECKER) {  // checkerboard.rs:34-44
+            uint32_t iu = as_u32_sat(u * R(2) / tx.scale);
+            uint32_t iv = as_u32_sat(v * R(2) / tx.scale);
+            t = ((iu + iv) % 2u) == 0u ? tx.aux : int32_t(tx.data);
+        } else if (tx.type == RT_TEX_CHECKER_SOLID) {  // checkerboard.rs:74-85
+            int32_t ix = as_i32_sat(floor(p.x / tx.scale));
+            int32_t iy = as_i32_sat(floor(p.y / tx.scale));
+            int32_t iz = as_i32_sat(floor(p.z / tx.scale));
+            int32_t sum = int32_t(uint32_t(ix) + uint32_t(iy) + uint32_t(iz));
+            t = (sum % 2) == 0 ? tx.aux : int32_t(tx.data);
+        } else if (tx.type == RT_TEX_UV_DEBUG) {
+            return mk<R>(u, v, R(0.5));  // uv_debug.rs:11-13
+        } else {
+            return ld3(tx.v);  // constant.rs:30
+        }
+    }
+}
+
+// Runs a postfix texture program (rt_scene.h) on a 4-deep value stack kept in registers: pushes and pops are
+// register moves, there is no indexed array.  Floats travel in .x.
+template <typename R> RT_DEV V3<R> eval_texture(const SceneView<R>& sc, int32_t prog, R u, R v, V3<R> p) {
+    const int32_t first = prog & ((1 << kTexProgShift) - 1), count = prog >> kTexProgShift;
+    V3<R> s0 = mk<R>(0, 0, 0), s1 = s0, s2 = s0, s3 = s0;  // s0 = top
+#pragma clang loop unroll(disable)
+    for (int32_t k = 0; k < count; k++) {
+        const TextureRec<R>& tx = sc.textures[first + k];
+        switch (tx.type) {
+            case RT_TEX_CHECKER: {  // checkerboard.rs:34-44; s1 = even, s0 = odd
+                uint32_t iu = as_u32_sat(u * R(2) / tx.scale);
+                uint32_t iv = as_u32_sat(v * R(2) / tx.scale);
+                s0 = ((iu + iv) % 2u) == 0u ? s1 : s0;
+                s1 = s2;
+                s2 = s3;
+                break;
+            }
+            case RT_TEX_CHECKER_SOLID: {  // checkerboard.rs:74-85
+                int32_t ix = as_i32_sat(floor(p.x / tx.scale));
+                int32_t iy = as_i32_sat(floor(p.y / tx.scale));
+                int32_t iz = as_i32_sat(floor(p.z / tx.scale));
+                int32_t sum = int32_t(uint32_t(ix) + uint32_t(iy) + uint32_t(iz));
+                s0 = (sum % 2) == 0 ? s1 : s0;
+                s1 = s2;
+                s2 = s3;
+                break;
+            }
+            case RT_TEX_LERP: {  // interpolate.rs:29-39; s2 = start, s1 = end, s0 = t
+                const R t = s0.x;
+                V3<R> r;
+                if (t == R(0)) r = s2;
+                else if (t == R(1)) r = s1;
+                else r = s2 * (R(1) - t) + s1 * t;
+                s0 = r;
+                s1 = s3;
+                break;
+            }
+            case RT_TEX_CHANNEL:  // channel.rs:22-25 (index 3 = the colour's w, always 0)
+                s0 = mk<R>(tx.aux == 0 ? s0.x : (tx.aux == 1 ? s0.y : (tx.aux == 2 ? s0.z : R(0))), R(0), R(0));
+                break;
+            default: {  // leaves push
+                V3<R> val;
+                if (tx.type == RT_TEX_UV_DEBUG) val = mk<R>(u, v, R(0.5));  // uv_debug.rs:11-13
+                else if (tx.type == RT_TEX_IMAGE) val = image_sample(sc, tx, u, v);
+                else if (tx.type == RT_TEX_NOISE_SOLID) val = mk<R>(noise_solid_sample(sc, tx, p), R(0), R(0));
+                else val = ld3(tx.v);  // constant.rs:30 (a float constant keeps its value in v[0])
+                s3 = s2;
+                s2 = s1;
+                s1 = s0;
+                s0 = val;
+                break;
+            }
+        }
+    }
+    return s0;
+}
+
 template <typename R>
 struct HitInfo {
     V3<R> pos, normal;
     R u, v;
+    V3<R> tex_a;  // the material's colour texture (albedo / emission) sampled at the hit
+    R tex_b;      // its float texture (roughness)
     int32_t material;
     bool front_face;
 };
 
-template <typename R>
+// TEX: the scene uses lerp / image / noise / channel textures or normal maps (CompiledScene::needs_tex_interpreter):
+// only then is the tangent frame built and the texture interpreter compiled in (it costs ~100 VGPRs in f64).
+template <typename R, bool TEX>
 RT_DEV HitInfo<R> resolve_hit(const SceneView<R>& sc, const Ray<R>& wray, const Best<R>& best) {
     const Op op = sc.ops[best.pc];
     const Ray<R> ray = ray_in_chain(sc, wray, op.chain);
     HitInfo<R> h;
     V3<R> outward;
+    // object-space tangent frame (HitRecord::tangent / bitangent, object.rs:36-37): only normal-mapped
+    // materials read it, and no Transform touches it on the way up (transform.rs:132-133)
+    V3<R> tangent = mk<R>(1, 0, 0), bitangent = mk<R>(1, 0, 0);
     h.u = R(0);
     h.v = R(0);
     switch (op.type) {
@@ -456,6 +607,10 @@ RT_DEV HitInfo<R> resolve_hit(const SceneView<R>& sc, const Ray<R>& wray, const 
             if (sc.materials[s.material].needs_uv) {
                 R theta = acos(outward.y);
                 R phi = atan2(-outward.z, outward.x) + pi<R>();
+                if constexpr (TEX) {
+                    tangent = mk<R>(-outward.z, R(0), -outward.x);  // sphere.rs:83-84
+                    bitangent = cross(outward, tangent);
+                }
                 h.u = phi / (R(2) * pi<R>());
                 h.v = theta / pi<R>();
             }
@@ -468,6 +623,10 @@ RT_DEV HitInfo<R> resolve_hit(const SceneView<R>& sc, const Ray<R>& wray, const 
             h.material = p.material;
             h.u = best.u;
             h.v = best.v;
+            if (TEX && sc.materials[p.material].has_normal_map) {  // plane.rs:96-97
+                tangent = to_unit(ld3(p.u));
+                bitangent = to_unit(ld3(p.v));
+            }
             break;
         }
         case OP_MESH: {  // mesh.rs:103-162
@@ -482,6 +641,19 @@ RT_DEV HitInfo<R> resolve_hit(const SceneView<R>& sc, const Ray<R>& wray, const 
                 outward = ld3(at.n0) * w + ld3(at.n1) * best.u + ld3(at.n2) * best.v;  // not normalised (SURVEY B-4)
             }
             if (at.has_uv) {
+                if (TEX && sc.materials[mi.material].has_normal_map) {  // mesh.rs:127-145
+                    const TriRec<R>& tr = sc.tris[best.tri];
+                    V3<R> edge1 = ld3(tr.e1), edge2 = ld3(tr.e2);
+                    R du1 = at.uv1[0] - at.uv0[0], dv1 = at.uv1[1] - at.uv0[1];
+                    R du2 = at.uv2[0] - at.uv0[0], dv2 = at.uv2[1] - at.uv0[1];
+                    V3<R> edge1perp = cross(outward, edge1);
+                    V3<R> edge2perp = cross(edge2, outward);
+                    tangent = edge2perp * du1 + edge1perp * du2;
+                    bitangent = edge2perp * dv1 + edge1perp * dv2;
+                    R inv_max = R(1) / sqrt(fmax(length_squared(tangent), length_squared(bitangent)));
+                    tangent = tangent * -inv_max;
+                    bitangent = bitangent * inv_max;
+                }
                 h.u = at.uv0[0] * w + at.uv1[0] * best.u + at.uv2[0] * best.v;
                 h.v = at.uv0[1] * w + at.uv1[1] * best.u + at.uv2[1] * best.v;
             }
@@ -516,47 +688,38 @@ RT_DEV HitInfo<R> resolve_hit(const SceneView<R>& sc, const Ray<R>& wray, const 
         h.pos = xform_apply(x.m, h.pos, R(1));
         h.normal = to_unit(xform_apply(x.m, h.normal, R(0)));
     }
-    return h;
-}
-
-// ------------------------------------------------------------------ textures (texture/*.rs)
-template <typename R> RT_DEV uint32_t as_u32_sat(R x) {  // Rust `as u32`
-    if (!(x > R(0))) return 0u;
-    if (x >= R(4294967295.0)) return 4294967295u;
-    return uint32_t(x);
-}
-template <typename R> RT_DEV int32_t as_i32_sat(R x) {
-    if (x != x) return 0;
-    if (x <= R(-2147483648.0)) return INT32_MIN;
-    if (x >= R(2147483647.0)) return INT32_MAX;
-    return int32_t(x);
-}
-// Walks checker nodes down to a leaf texture (checkerboard.rs:34-44, 74-85).
-template <typename R> RT_DEV int32_t texture_leaf(const SceneView<R>& sc, int32_t t, R u, R v, V3<R> p) {
-    for (;;) {
-        const TextureRec<R>& tx = sc.textures[t];
-        if (tx.type == RT_TEX_CHECKER) {
-            uint32_t iu = as_u32_sat(u * R(2) / tx.scale);
-            uint32_t iv = as_u32_sat(v * R(2) / tx.scale);
-            t = ((iu + iv) % 2u) == 0u ? tx.a : tx.b;
-        } else if (tx.type == RT_TEX_CHECKER_SOLID) {
-            int32_t ix = as_i32_sat(floor(p.x / tx.scale));
-            int32_t iy = as_i32_sat(floor(p.y / tx.scale));
-            int32_t iz = as_i32_sat(floor(p.z / tx.scale));
-            int32_t s = int32_t(uint32_t(ix) + uint32_t(iy) + uint32_t(iz));
-            t = (s % 2) == 0 ? tx.a : tx.b;
-        } else {
-            return t;
+    // The material's textures are sampled HERE, once, in one non-unrolled loop: a single inlined copy of the
+    // texture interpreter (image fetch, Perlin turbulence) instead of one per use in shade().  Samplers are
+    // pure functions of (u, v, p), so sampling a texture the material then does not read changes nothing.
+    //   slot 0: normal map -> Glossy / NormalDebug use the mapped normal wherever they use the normal
+    //           (glossy.rs:35-50, normal_debug.rs:23-39): columns (tangent, bitangent, normal) x (sample - 0.5)
+    //   slot 1: tex_a (albedo / emission), slot 2: tex_b (roughness)
+    const MaterialRec& mat = sc.materials[h.material];
+    h.tex_a = mk<R>(0, 0, 0);
+    h.tex_b = R(0);
+    if constexpr (!TEX) {
+        if (mat.tex_a >= 0) h.tex_a = eval_texture_simple(sc, mat.tex_a, h.u, h.v, h.pos);
+        if (mat.tex_b >= 0) h.tex_b = eval_texture_simple(sc, mat.tex_b, h.u, h.v, h.pos).x;
+    } else {
+#pragma clang loop unroll(disable)
+        for (int slot = 0; slot < 3; slot++) {
+            const int32_t prog = slot == 0 ? (mat.has_normal_map ? mat.tex_c : -1) : (slot == 1 ? mat.tex_a : mat.tex_b);
+            if (prog < 0) continue;
+            const V3<R> val = eval_texture(sc, prog, h.u, h.v, h.pos);
+            if (slot == 0) {
+                V3<R> smp = val - mk<R>(R(0.5), R(0.5), R(0.5));
+                V3<R> m = mk<R>(tangent.x * smp.x + bitangent.x * smp.y + h.normal.x * smp.z,
+                                tangent.y * smp.x + bitangent.y * smp.y + h.normal.y * smp.z,
+                                tangent.z * smp.x + bitangent.z * smp.y + h.normal.z * smp.z);
+                h.normal = to_unit(m);
+            } else if (slot == 1) {
+                h.tex_a = val;
+            } else {
+                h.tex_b = val.x;
+            }
         }
     }
-}
-template <typename R> RT_DEV V3<R> sample_color(const SceneView<R>& sc, int32_t t, const HitInfo<R>& h) {
-    const TextureRec<R>& tx = sc.textures[texture_leaf(sc, t, h.u, h.v, h.pos)];
-    if (tx.type == RT_TEX_UV_DEBUG) return mk<R>(h.u, h.v, R(0.5));  // uv_debug.rs:11-13
-    return ld3(tx.v);                                                // constant.rs:30
-}
-template <typename R> RT_DEV R sample_float(const SceneView<R>& sc, int32_t t, const HitInfo<R>& h) {
-    return sc.textures[texture_leaf(sc, t, h.u, h.v, h.pos)].v[0];
+    return h;
 }
 
 // ------------------------------------------------------------------ lights (pdf/hittable.rs + Hit::pdf_value / random)
@@ -677,13 +840,13 @@ struct PathState {
 };
 
 // Shades the closest hit; returns true if the path continues with ps.ray updated.
-template <typename R, bool STATS>
+template <typename R, bool STATS, bool TEX = false>
 RT_DEV bool shade(const SceneView<R>& sc, const ParamsView<R>& prm, PathState<R>& ps, const Best<R>& best, Rng& rng, LaneCounters& cnt) {
     if (best.pc < 0) {  // camera.rs:331 background
         ps.radiance = ps.radiance + ps.throughput * ld3(prm.background);
         return false;
     }
-    const HitInfo<R> hit = resolve_hit(sc, ps.ray, best);
+    const HitInfo<R> hit = resolve_hit<R, TEX>(sc, ps.ray, best);
     const MaterialRec mat = sc.materials[hit.material];
     V3<R> attenuation;
     V3<R> pdf_w;          // CosinePDF::w (the shading normal), cosine.rs:17-22
@@ -691,7 +854,7 @@ RT_DEV bool shade(const SceneView<R>& sc, const ParamsView<R>& prm, PathState<R>
     bool uniform_pdf = false;
     switch (mat.type) {
         case RT_MAT_EMISSIVE: {  // emissive.rs:24-34; camera.rs:327
-            if (hit.front_face) ps.radiance = ps.radiance + ps.throughput * sample_color(sc, mat.tex_a, hit);
+            if (hit.front_face) ps.radiance = ps.radiance + ps.throughput * hit.tex_a;
             return false;
         }
         case RT_MAT_NORMAL_DEBUG: {  // normal_debug.rs:42-48
@@ -699,20 +862,20 @@ RT_DEV bool shade(const SceneView<R>& sc, const ParamsView<R>& prm, PathState<R>
             return false;
         }
         case RT_MAT_LAMBERTIAN:  // lambertian.rs:25-33
-            attenuation = sample_color(sc, mat.tex_a, hit);
+            attenuation = hit.tex_a;
             pdf_w = hit.normal;
             with_pdf = true;
             break;
         case RT_MAT_ISOTROPIC:  // isotropic.rs:25-33
-            attenuation = sample_color(sc, mat.tex_a, hit);
+            attenuation = hit.tex_a;
             with_pdf = true;
             uniform_pdf = true;
             break;
         case RT_MAT_METAL: {  // metal.rs:28-44
             V3<R> reflected = reflect(ps.ray.d, hit.normal);
-            V3<R> scatter_dir = reflected + random_unit<R>(rng) * sample_float(sc, mat.tex_b, hit) * length(reflected);
+            V3<R> scatter_dir = reflected + random_unit<R>(rng) * hit.tex_b * length(reflected);
             if (!(dot(scatter_dir, hit.normal) > R(0))) return false;  // Absorbed (camera.rs:326)
-            ps.throughput = ps.throughput * sample_color(sc, mat.tex_a, hit);
+            ps.throughput = ps.throughput * hit.tex_a;
             ps.ray = make_ray(hit.pos, scatter_dir);
             return true;
         }
@@ -734,14 +897,14 @@ RT_DEV bool shade(const SceneView<R>& sc, const ParamsView<R>& prm, PathState<R>
             R cos_theta = fmin(R(1), dot(-unit_dir, normal));
             bool specular = reflectance(cos_theta, sc.material_params[hit.material].inv_ior) > rng_uniform<R>(rng);
             if (specular) {
-                R roughness = sample_float(sc, mat.tex_b, hit);
+                R roughness = hit.tex_b;
                 V3<R> reflected = reflect(ps.ray.d, normal);
                 V3<R> scatter_dir = reflected + random_unit<R>(rng) * roughness * length(reflected);
                 if (!(dot(scatter_dir, normal) > R(0))) return false;  // Absorbed
                 ps.ray = make_ray(hit.pos, scatter_dir);               // attenuation (1,1,1)
                 return true;
             }
-            attenuation = sample_color(sc, mat.tex_a, hit);
+            attenuation = hit.tex_a;
             pdf_w = normal;
             with_pdf = true;
             break;

@@ -33,7 +33,7 @@ template <typename R> RT_DEV uint32_t row_to_y(const ParamsView<R>& prm, uint32_
 // world_test -> shade and no lane idles while it still has samples.  Sums are accumulated
 // per pixel in the reference's order, so the result does not depend on scheduling.
 // ---------------------------------------------------------------------------------------------
-template <typename R, bool STATS>
+template <typename R, bool STATS, bool TEX>
 __global__ void __launch_bounds__(256) k_megakernel(SceneView<R> sc, CameraView<R> cam, ParamsView<R> prm,
                                                     double* __restrict__ out, DeviceCounters* counters) {
     extern __shared__ int lds_stack[];
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) k_megakernel(SceneView<R> sc, CameraView<
         if (ps.depth != 0) {  // camera.rs:290
             Best<R> best;
             world_test<R, STATS>(sc, ps.ray, R(0.001), best, stack, stride, cnt);
-            cont = shade<R, STATS>(sc, prm, ps, best, rng, cnt);
+            cont = shade<R, STATS, TEX>(sc, prm, ps, best, rng, cnt);
             ps.depth--;
         }
         if (!cont) {
@@ -137,7 +137,7 @@ __global__ void k_trace_sample(SceneView<R> sc, CameraView<R> cam, ParamsView<R>
             t[0] = double(best.t);
             t[4] = -1; t[5] = -1; t[6] = double(best.tri);
             if (best.pc >= 0) {
-                HitInfo<R> h = resolve_hit(sc, ps.ray, best);
+                HitInfo<R> h = resolve_hit<R, true>(sc, ps.ray, best);
                 t[1] = double(h.pos.x); t[2] = double(h.pos.y); t[3] = double(h.pos.z);
                 t[4] = double(h.material);
                 t[5] = double(sc.ops[best.pc].type);
@@ -147,7 +147,7 @@ __global__ void k_trace_sample(SceneView<R> sc, CameraView<R> cam, ParamsView<R>
             t[14] = double(ps.ray.d.x); t[15] = double(ps.ray.d.y); t[16] = double(ps.ray.d.z);
         }
         n++;
-        bool cont = shade<R, false>(sc, prm, ps, best, rng, cnt);
+        bool cont = shade<R, false, true>(sc, prm, ps, best, rng, cnt);  // the general (interpreter) texture path
         ps.depth--;
         if (!cont) break;
     }
@@ -325,10 +325,13 @@ struct DeviceScene {
         std::vector<TextureRec<R>> textures(cs.textures.size());
         for (size_t i = 0; i < textures.size(); i++) {
             const auto& s = cs.textures[i];
-            textures[i].type = s.type; textures[i].a = s.a; textures[i].b = s.b; textures[i].c = s.c;
+            textures[i].type = s.type; textures[i].aux = s.aux; textures[i].data = s.data;
+            textures[i].width = s.width; textures[i].height = s.height; textures[i]._pad = 0;
             cast_arr(textures[i].v, s.v);
             textures[i].scale = R(s.scale);
         }
+        std::vector<R> perlin_vec(cs.perlin_vec.size());
+        for (size_t i = 0; i < perlin_vec.size(); i++) perlin_vec[i] = R(cs.perlin_vec[i]);
         int st;
         if ((st = buf.upload(cs.ops, &view.ops)) != RT_OK) return st;
         if ((st = buf.upload(bounds, &view.bounds)) != RT_OK) return st;
@@ -347,6 +350,9 @@ struct DeviceScene {
         if ((st = buf.upload(cs.materials, &view.materials)) != RT_OK) return st;
         if ((st = buf.upload(mparams, &view.material_params)) != RT_OK) return st;
         if ((st = buf.upload(textures, &view.textures)) != RT_OK) return st;
+        if ((st = buf.upload(cs.texels, &view.texels)) != RT_OK) return st;
+        if ((st = buf.upload(perlin_vec, &view.perlin_vec)) != RT_OK) return st;
+        if ((st = buf.upload(cs.perlin_perm, &view.perlin_perm)) != RT_OK) return st;
         if ((st = buf.upload(cs.lights, &view.lights)) != RT_OK) return st;
         // the same small tables once more, packed for LDS staging
         {
@@ -466,10 +472,11 @@ int render_typed(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, const 
     if (lds > 160 * 1024) return set_err(RT_E_UNSUPPORTED, "mesh BVH too deep for the LDS traversal stack");
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    if (p.collect_stats)
-        hipLaunchKernelGGL((k_megakernel<R, true>), grid, block, lds, stream, ds.view, cv, pv, d_out, s->d_counters);
-    else
-        hipLaunchKernelGGL((k_megakernel<R, false>), grid, block, lds, stream, ds.view, cv, pv, d_out, s->d_counters);
+    const bool tex = s->compiled.needs_tex_interpreter;  // lerp / image / noise / channel / normal maps: interpreter variant
+#define RT_LAUNCH_MEGA(ST, TX) hipLaunchKernelGGL((k_megakernel<R, ST, TX>), grid, block, lds, stream, ds.view, cv, pv, d_out, s->d_counters)
+    if (p.collect_stats) { if (tex) RT_LAUNCH_MEGA(true, true); else RT_LAUNCH_MEGA(true, false); }
+    else { if (tex) RT_LAUNCH_MEGA(false, true); else RT_LAUNCH_MEGA(false, false); }
+#undef RT_LAUNCH_MEGA
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -632,6 +639,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     const bool lds_tables = ds.view.lay.total_bytes <= 48u * 1024u && env_u32("RT_LDS_TABLES", 1) != 0;
     const size_t lds_small = lds_tables ? size_t(ds.view.lay.total_bytes) : 0;
     const uint32_t check_every = env_u32("RT_WF_CHECK", 8);
+    const bool tex = s->compiled.needs_tex_interpreter;
 
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
@@ -679,9 +687,11 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
                         hipLaunchKernelGGL((k_wf_intersect<R, false>), dim3(isect_blocks), dim3(256), lds, stream, ds.view, pool, w.queue[qi], w.d_ctr, s->d_counters, refill_min);
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 }
-#define RT_LAUNCH_SHADE(ST, L) hipLaunchKernelGGL((k_wf_shade<R, ST, L>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), lds_small + (2 * WF_CHUNK + 8) * 4, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters)
-                if (stats) { if (lds_tables) RT_LAUNCH_SHADE(true, true); else RT_LAUNCH_SHADE(true, false); }
-                else { if (lds_tables) RT_LAUNCH_SHADE(false, true); else RT_LAUNCH_SHADE(false, false); }
+#define RT_LAUNCH_SHADE(ST, L, TX) hipLaunchKernelGGL((k_wf_shade<R, ST, L, TX>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), (L ? lds_small : size_t(0)) + (2 * WF_CHUNK + 8) * 4, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters)
+                if (tex) {  // interpreter variant: tables from global memory (rare scenes, fewer instantiations)
+                    if (stats) RT_LAUNCH_SHADE(true, false, true); else RT_LAUNCH_SHADE(false, false, true);
+                } else if (stats) { if (lds_tables) RT_LAUNCH_SHADE(true, true, false); else RT_LAUNCH_SHADE(true, false, false); }
+                else { if (lds_tables) RT_LAUNCH_SHADE(false, true, false); else RT_LAUNCH_SHADE(false, false, false); }
 #undef RT_LAUNCH_SHADE
                 hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(1), 0, stream, w.d_ctr);
                 qi ^= 1;

@@ -119,7 +119,7 @@ struct MaterialRec {  // material/*.rs
     int32_t type;     // RtMaterialType
     int32_t tex_a, tex_b, tex_c;
     int32_t needs_uv; // any reachable texture reads (u, v)
-    int32_t _pad;
+    int32_t has_normal_map;  // tex_c is a normal map (glossy.rs:35-50, normal_debug.rs:23-39): tangent frame needed
 };
 template <typename R>
 struct MaterialParams {
@@ -127,13 +127,26 @@ struct MaterialParams {
     R inv_ior;  // Glossy::inv_ior = 1 / ior (glossy.rs:30), computed in f64 then rounded
 };
 
+// Texture expressions are compiled to POSTFIX programs (rt_compile.cpp): a material slot holds
+// (first op | op count << 20); operands are evaluated before their operator onto a 4-deep value stack:
+//   CONST_COLOR / CONST_FLOAT / UV_DEBUG / IMAGE / NOISE_SOLID   push a value
+//   CHECKER / CHECKER_SOLID   [even][odd] -> the one the parity rule selects (checkerboard.rs:34-44, 74-85)
+//   LERP                      [start][end][t] -> interpolate.rs:29-39
+//   CHANNEL                   [colour] -> colour[channel] (channel.rs:22-25)
+// Every sampler is a pure function of (u, v, p), so evaluating both inputs of a checker / lerp and
+// selecting afterwards gives the reference's value.
 template <typename R>
 struct TextureRec {  // texture/*.rs
     int32_t type;    // RtTextureType
-    int32_t a, b, c;
-    R v[3];
-    R scale;
+    int32_t aux;     // CHANNEL: channel index; NOISE_SOLID: turbulence samples
+    uint32_t data;   // IMAGE: first texel (in RGB triples) in SceneView::texels; NOISE_SOLID: generator index
+    uint32_t width, height;  // IMAGE
+    int32_t _pad;
+    R v[3];          // CONST_*: value; NOISE_SOLID: scale vector
+    R scale;         // CHECKER*
 };
+constexpr int kTexStackDepth = 4;
+constexpr int32_t kTexProgShift = 20;  // program id = first op | (op count << 20)
 
 enum LightKind : int32_t { LIGHT_OTHER = 0, LIGHT_PLANE = 1, LIGHT_SPHERE = 2, LIGHT_SKY = 3, LIGHT_SUN = 4 };
 struct LightRec {
@@ -169,7 +182,10 @@ struct SceneView {
     const TriAttr<R>* attrs;
     const MaterialRec* materials;
     const MaterialParams<R>* material_params;
-    const TextureRec<R>* textures;
+    const TextureRec<R>* textures;   // postfix ops
+    const float* texels;             // all image textures, RGB f32 triples (image.rs / buffer.rs:30-48)
+    const R* perlin_vec;             // per generator: 256 x (x, y, z)   (perlin.rs:13-18)
+    const uint32_t* perlin_perm;     // per generator: perm_x, perm_y, perm_z (3 x 256)
     const LightRec* lights;
     int32_t n_lights;
     int32_t lights_is_list;  // lights root is an ObjectList (list.rs:80-100) vs a single object

@@ -780,7 +780,7 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
 // ---------------------------------------------------------------------------------------------
 // Shade: one path vertex per lane (camera.rs:295-331), regeneration and queue compaction.
 // ---------------------------------------------------------------------------------------------
-template <typename R, bool STATS, bool LDS>
+template <typename R, bool STATS, bool LDS, bool TEX>
 __global__ void __launch_bounds__(256) k_wf_shade(SceneView<R> sc_g, CameraView<R> cam, ParamsView<R> prm, WfPool<R> pool, WfGroup<R> grp,
                                                   const uint32_t* __restrict__ queue_in, uint32_t* __restrict__ queue_out,
                                                   WfCounters* __restrict__ ctr, double* __restrict__ sample_L, DeviceCounters* counters) {
@@ -819,7 +819,7 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneView<R> sc_g, CameraView<
         best.pc = pool.hpc[slot]; best.tri = pool.htri[slot];
         Rng rng;
         rng.s = pool.rng[slot];
-        bool cont = shade<R, STATS>(sc, prm, ps, best, rng, cnt);
+        bool cont = shade<R, STATS, TEX>(sc, prm, ps, best, rng, cnt);
         ps.depth--;
         if (cont && ps.depth != 0) {  // depth == 0: ray_color returns black without tracing (camera.rs:290)
             pool.ox[slot] = ps.ray.o.x; pool.oy[slot] = ps.ray.o.y; pool.oz[slot] = ps.ray.o.z;

@@ -21,6 +21,9 @@ CASES = {
     "hollow_glass": ["tests/scenes/hollow_glass", "-w=48", "-s=16", "--seed=3"],
     "nested_transform": ["tests/scenes/nested_transform", "-w=48", "-s=8", "-t=2", "--seed=4"],
     "default": ["-w=60", "-s=16", "--seed=5"],
+    "perlin": ["scenes/perlin", "-w=48", "-s=16", "--seed=12"],
+    "texture_test": ["scenes/texture_test", "-w=48", "-s=16", "--seed=14"],
+    "texture_mix": ["tests/scenes/texture_mix", "-w=48", "-s=16", "--seed=15"],
 }
 
 

@@ -36,6 +36,11 @@ SCENES = {
     "test": ["scenes/test", "-w=45", "-s=16", "--seed=9"],
     "tonemap_test": ["scenes/tonemap_test", "-w=40", "-s=16", "--seed=10"],
     "two_meshes": ["tests/scenes/two_meshes", "-w=48", "-s=16", "--seed=11"],   # >1 mesh op: combined intersect kernel
+    # texture interpreter variants of the kernels (image / noise / lerp / channel textures, normal maps)
+    "perlin": ["scenes/perlin", "-w=48", "-s=16", "--seed=12"],
+    "earth": ["scenes/earth", "-w=48", "-s=16", "--seed=13"],          # JPEG texture on a sphere
+    "texture_test": ["scenes/texture_test", "-w=48", "-s=16", "--seed=14"],  # PNG albedo / roughness channel / normal map on a mesh
+    "texture_mix": ["tests/scenes/texture_mix", "-w=48", "-s=16", "--seed=15"],  # every operator, every primitive's tangent frame
 }
 
 
@@ -99,7 +104,7 @@ def test_f64_matches_committed_golden_frames(dev, name):
     assert_f64_parity(gpu, GOLD[name])
 
 
-@pytest.mark.parametrize("name", ["cornell", "light_test", "default", "nested_transform", "sun_sky"])
+@pytest.mark.parametrize("name", ["cornell", "light_test", "default", "nested_transform", "sun_sky", "texture_mix"])
 def test_f32_is_statistically_equivalent(dev, name):
     args = [a for a in SCENES[name] if not a.startswith("-s=")] + ["-s=64"]
     hs = api.HostScene(args)
@@ -114,7 +119,7 @@ def test_f32_is_statistically_equivalent(dev, name):
     assert close.mean() >= 0.95, f"only {close.mean():.3%} of f32 values are close to the f64 oracle"
 
 
-@pytest.mark.parametrize("name", ["cornell", "hollow_glass", "default", "light_test", "two_meshes"])
+@pytest.mark.parametrize("name", ["cornell", "hollow_glass", "default", "light_test", "two_meshes", "texture_mix"])
 def test_every_kernel_variant_is_bit_identical(dev, name, monkeypatch):
     """The wavefront kernels exist in several template variants (counters on/off, small tables in
     LDS or global memory, split or combined intersect).  hipcc (ROCm 7.2) has produced wrong Dielectric
