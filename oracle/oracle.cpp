@@ -1517,6 +1517,26 @@ int oracle_lights_random(const RtSceneDesc* scene, const double o[3], uint64_t s
     return RT_OK;
 }
 
+// Samples texture `tex` of the scene at (u, v, p): colour textures fill out3, float textures out3[0].
+int oracle_texture_sample(const RtSceneDesc* scene, uint32_t tex, double u, double v, const double p[3], double* out3) {
+    g_err.clear();
+    if (!scene || scene->abi_version != RT_MI355_ABI_VERSION) { g_err = "bad scene description"; return RT_E_INVALID; }
+    World w;
+    w.color_tex.resize(scene->n_textures);
+    w.float_tex.resize(scene->n_textures);
+    Builder b{*scene, w, std::vector<int>(scene->n_textures, 0)};
+    if (!b.build_texture(int(tex))) return RT_E_INVALID;
+    Vec4 pt = point(p[0], p[1], p[2]);
+    if (b.tex_state[tex] == 1) {
+        Vec4 c = w.color_tex[tex]->sample(u, v, pt);
+        out3[0] = c[0]; out3[1] = c[1]; out3[2] = c[2];
+    } else {
+        out3[0] = w.float_tex[tex]->sample(u, v, pt);
+        out3[1] = out3[2] = 0.0;
+    }
+    return RT_OK;
+}
+
 void oracle_detmath(double x, double* out3) {
     det_sincos(x, &out3[0], &out3[1]);
     out3[2] = x > 0 ? det_log(x) : 0.0;

@@ -65,6 +65,8 @@ int oracle_lights_random(const RtSceneDesc* scene, const double origin[3], uint6
 /* include/rt_detmath.h: out3 = det_sin(x), det_cos(x), det_log(x) */
 void oracle_detmath(double x, double* out3);
 /* utils.rs:31-36 */
+/* texture/*.rs Sampler::sample of texture `tex` at (u, v, p) */
+int oracle_texture_sample(const RtSceneDesc* scene, uint32_t tex, double u, double v, const double p[3], double* out3);
 double oracle_reflectance(double cos_theta, double ior_ratio);
 /* utils.rs:17-28: out9 = columns u, v, w */
 void oracle_onb_from_vec(const double w[3], double* out9);

@@ -54,6 +54,8 @@ def load() -> C.CDLL:
         lib.oracle_lights_random.restype = C.c_int
         lib.oracle_detmath.argtypes = [C.c_double, dp]
         lib.oracle_detmath.restype = None
+        lib.oracle_texture_sample.argtypes = [C.POINTER(api.RtSceneDesc), C.c_uint32, C.c_double, C.c_double, dp, dp]
+        lib.oracle_texture_sample.restype = C.c_int
         lib.oracle_reflectance.argtypes = [C.c_double, C.c_double]
         lib.oracle_reflectance.restype = C.c_double
         lib.oracle_onb_from_vec.argtypes = [dp, dp]
@@ -179,6 +181,15 @@ def lights_random(desc, origin, seed, n) -> np.ndarray:
     if st != 0:
         raise api.RtError(st, lib.oracle_last_error().decode())
     return np.array(list(out)).reshape(n, 3)
+
+
+def texture_sample(desc, tex, u, v, p=(0.0, 0.0, 0.0)) -> np.ndarray:
+    lib = load()
+    out = (C.c_double * 3)()
+    st = lib.oracle_texture_sample(desc, tex, u, v, _d3(p), out)
+    if st != 0:
+        raise api.RtError(st, lib.oracle_last_error().decode())
+    return np.array(list(out))
 
 
 def reflectance(cos_theta, ior_ratio) -> float:
