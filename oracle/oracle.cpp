@@ -990,7 +990,8 @@ struct Volume : Hit {
                 t_min = std::fmax(t_min, 0.0);
                 double ray_len = length(ray.dir);
                 double dist_inside_boundary = (t_max - t_min) * ray_len;
-                double hit_dist = neg_inv_density * det_log(rng.uniform());
+                double uu = rng.uniform();
+                double hit_dist = neg_inv_density * (uu == 0.0 ? -INF : det_log(uu));  // f64::ln(0) = -inf
                 if (hit_dist > dist_inside_boundary) return false;
                 double tt = t_min + hit_dist / ray_len;
                 Vec4 hit_pos = ray.at(tt);

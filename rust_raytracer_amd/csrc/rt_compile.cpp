@@ -196,6 +196,8 @@ struct Compiler {
         return true;
     }
 
+    bool in_volume = false;
+
     bool compile_node(uint32_t node, int depth) {
         if (status != RT_OK) return false;
         if (node >= d.n_nodes) return fail(RT_E_INVALID, "node index out of range");
@@ -272,8 +274,27 @@ struct Compiler {
             }
             case RT_NODE_NULL:
                 return true;  // NullObject::test never hits (null_obj.rs:17)
-            case RT_NODE_VOLUME:
-                return fail(RT_E_UNSUPPORTED, "volume objects are not supported by the HIP kernels yet");
+            case RT_NODE_VOLUME: {  // volume.rs:33-71: the boundary's sub-program is emitted twice (entry search, exit search)
+                if (n.n_children != 1) return fail(RT_E_INVALID, "volume node needs one child (its boundary)");
+                if (in_volume) return fail(RT_E_UNSUPPORTED, "a volume inside another volume's boundary is not supported");
+                if (!check_material(n.material)) return false;
+                VolumeRec<double> v{};
+                v.neg_inv_density = -1.0 / n.p[0];  // Volume::new (volume.rs:23)
+                v.material = n.material;
+                out.volumes.push_back(v);
+                const int32_t vi = int32_t(out.volumes.size()) - 1;
+                in_volume = true;
+                emit(OP_VOL_BEGIN, vi);
+                bool ok = compile_node(kids[0], depth + 1);
+                const size_t mid = out.ops.size();
+                emit(OP_VOL_MID, vi);
+                ok = ok && compile_node(kids[0], depth + 1);
+                emit(OP_VOL_END, vi);
+                in_volume = false;
+                if (!ok) return false;
+                out.ops[mid].skip = int32_t(out.ops.size());
+                return true;
+            }
             default:
                 return fail(RT_E_INVALID, "unknown node type");
         }

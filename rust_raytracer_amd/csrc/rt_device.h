@@ -328,8 +328,11 @@ template <typename R> RT_DEV Ray<R> ray_in_chain(const SceneView<R>& sc, const R
 // Reproduces ObjectList::test (list.rs:58-74), BoundingVolumeHierarchyNode::test
 // (bvh.rs:84-101) and Transform::test (transform.rs:122-139): depth-first, fixed order,
 // every test sees the interval (t_lo, closest_t so far).
-template <typename R, bool STATS>
-RT_DEV void world_test(const SceneView<R>& sc, const Ray<R>& wray, R t_lo, Best<R>& best, int* stack, int stride, LaneCounters& cnt) {
+// VOL: the program may contain volume ops (OP_VOL_*), which draw from the path's RNG during the search
+// (volume.rs:47); `rng` may be null otherwise.
+template <typename R, bool STATS, bool VOL = false>
+RT_DEV void world_test(const SceneView<R>& sc, const Ray<R>& wray, const R t_lo_outer, Best<R>& best, int* stack, int stride, LaneCounters& cnt,
+                       Rng* rng = nullptr) {
     best.t = Lim<R>::inf();
     best.pc = -1;
     best.tri = -1;
@@ -337,11 +340,62 @@ RT_DEV void world_test(const SceneView<R>& sc, const Ray<R>& wray, R t_lo, Best<
     best.v = R(0);
     Ray<R> cur = wray;
     int32_t pc = 0;
+    R t_lo = t_lo_outer;   // lower end of the current search interval (changes only inside a volume's boundary tests)
+    Best<R> saved = best;  // the caller's search state while a volume tests its boundary
+    R vol_enter = R(0);
     if (STATS) cnt.rays++;
     for (;;) {
         const Op op = sc.ops[pc];
         if (op.type == OP_END) break;
         switch (op.type) {
+            case OP_VOL_BEGIN:  // boundary.test(ray, Interval::UNIVERSE) (volume.rs:34)
+                if constexpr (VOL) {
+                    saved = best;
+                    best.t = Lim<R>::inf();
+                    best.pc = -1;
+                    t_lo = -Lim<R>::inf();
+                }
+                break;
+            case OP_VOL_MID:  // boundary.test(ray, (t_enter + 0.0001, inf)) (volume.rs:35-37)
+                if constexpr (VOL) {
+                    if (best.pc < 0) {
+                        best = saved;
+                        t_lo = t_lo_outer;
+                        pc = op.skip;
+                        continue;
+                    }
+                    vol_enter = best.t;
+                    t_lo = vol_enter + R(0.0001);
+                    best.t = Lim<R>::inf();
+                    best.pc = -1;
+                }
+                break;
+            case OP_VOL_END:  // volume.rs:38-68
+                if constexpr (VOL) {
+                    const bool has_exit = best.pc >= 0;
+                    const R t_exit = best.t;
+                    best = saved;
+                    t_lo = t_lo_outer;
+                    if (has_exit) {
+                        R t_min = fmax(vol_enter, t_lo_outer);
+                        R t_max = fmin(t_exit, best.t);
+                        if (!(t_min >= t_max)) {
+                            t_min = fmax(t_min, R(0));
+                            R ray_len = length(cur.d);
+                            R dist_inside = (t_max - t_min) * ray_len;
+                            R uu = rng_uniform<R>(*rng);
+                            R hit_dist = sc.volumes[op.arg].neg_inv_density * (uu == R(0) ? -Lim<R>::inf() : log_r(uu));
+                            if (!(hit_dist > dist_inside)) {
+                                best.t = t_min + hit_dist / ray_len;
+                                best.pc = pc;
+                                best.tri = -1;
+                                best.u = R(0);
+                                best.v = R(0);
+                            }
+                        }
+                    }
+                }
+                break;
             case OP_BOUNDS:
                 if (!test_bounding_box(sc.bounds[op.arg], cur, t_lo, best.t)) {
                     pc = op.skip;
@@ -669,6 +723,12 @@ RT_DEV HitInfo<R> resolve_hit(const SceneView<R>& sc, const Ray<R>& wray, const 
                 h.u = atan2(unit_dir.x, unit_dir.z) / (R(2) * pi<R>()) + R(0.5);
                 h.v = dot(unit_dir, mk<R>(0, 1, 0)) / R(2) + R(0.5);
             }
+            break;
+        }
+        case OP_VOL_END: {  // volume.rs:55-66: position on the ray, everything else arbitrary
+            h.pos = ray_at(ray, best.t);
+            outward = mk<R>(1, 0, 0);
+            h.material = sc.volumes[op.arg].material;
             break;
         }
         default: {  // OP_SUN, sun.rs:45-60

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) k_megakernel(SceneView<R> sc, CameraView<
         bool cont = false;
         if (ps.depth != 0) {  // camera.rs:290
             Best<R> best;
-            world_test<R, STATS>(sc, ps.ray, R(0.001), best, stack, stride, cnt);
+            world_test<R, STATS, TEX>(sc, ps.ray, R(0.001), best, stack, stride, cnt, &rng);  // TEX variant = full feature set (+ volumes)
             cont = shade<R, STATS, TEX>(sc, prm, ps, best, rng, cnt);
             ps.depth--;
         }
@@ -130,7 +130,7 @@ __global__ void k_trace_sample(SceneView<R> sc, CameraView<R> cam, ParamsView<R>
     uint32_t n = 0;
     while (ps.depth != 0) {
         Best<R> best;
-        world_test<R, false>(sc, ps.ray, R(0.001), best, lds_stack, int(blockDim.x), cnt);
+        world_test<R, false, true>(sc, ps.ray, R(0.001), best, lds_stack, int(blockDim.x), cnt, &rng);
         if (n < max_bounces) {
             double* t = trace + 17 * n;
             for (int k = 0; k < 17; k++) t[k] = 0;
@@ -330,6 +330,12 @@ struct DeviceScene {
             cast_arr(textures[i].v, s.v);
             textures[i].scale = R(s.scale);
         }
+        std::vector<VolumeRec<R>> volumes(cs.volumes.size());
+        for (size_t i = 0; i < volumes.size(); i++) {
+            volumes[i].neg_inv_density = R(cs.volumes[i].neg_inv_density);
+            volumes[i].material = cs.volumes[i].material;
+            volumes[i]._pad = 0;
+        }
         std::vector<R> perlin_vec(cs.perlin_vec.size());
         for (size_t i = 0; i < perlin_vec.size(); i++) perlin_vec[i] = R(cs.perlin_vec[i]);
         int st;
@@ -342,6 +348,7 @@ struct DeviceScene {
         if ((st = buf.upload(planes, &view.planes)) != RT_OK) return st;
         if ((st = buf.upload(suns, &view.suns)) != RT_OK) return st;
         if ((st = buf.upload(cs.meshes, &view.meshes)) != RT_OK) return st;
+        if ((st = buf.upload(volumes, &view.volumes)) != RT_OK) return st;
         if ((st = buf.upload(nodes, &view.nodes)) != RT_OK) return st;
         if ((st = buf.upload(nodes4, &view.nodes4)) != RT_OK) return st;
         if ((st = buf.upload(mesh_bounds, &view.mesh_bounds)) != RT_OK) return st;
@@ -472,7 +479,8 @@ int render_typed(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, const 
     if (lds > 160 * 1024) return set_err(RT_E_UNSUPPORTED, "mesh BVH too deep for the LDS traversal stack");
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    const bool tex = s->compiled.needs_tex_interpreter;  // lerp / image / noise / channel / normal maps: interpreter variant
+    // full-feature variant: texture interpreter (lerp / image / noise / channel / normal maps) and volumes
+    const bool tex = s->compiled.needs_tex_interpreter || !s->compiled.volumes.empty();
 #define RT_LAUNCH_MEGA(ST, TX) hipLaunchKernelGGL((k_megakernel<R, ST, TX>), grid, block, lds, stream, ds.view, cv, pv, d_out, s->d_counters)
     if (p.collect_stats) { if (tex) RT_LAUNCH_MEGA(true, true); else RT_LAUNCH_MEGA(true, false); }
     else { if (tex) RT_LAUNCH_MEGA(false, true); else RT_LAUNCH_MEGA(false, false); }
@@ -842,6 +850,13 @@ int rt_render_device(const RtScene* scene, const RtCameraDesc* camera, const RtR
     bool has_mesh = !s->compiled.meshes.empty();
     bool wavefront = params->pipeline == RT_PIPELINE_WAVEFRONT || (params->pipeline == RT_PIPELINE_AUTO && has_mesh);
     if (params->max_depth == 0) wavefront = false;  // every sample is black (camera.rs:290): nothing to schedule
+    if (!s->compiled.volumes.empty()) {
+        // Volume::test draws from the path's RNG in the middle of the closest-hit search, in program order; the
+        // wavefront scheduler splits that search over kernels.  Volumes therefore run on the megakernel.
+        if (params->pipeline == RT_PIPELINE_WAVEFRONT)
+            return set_err(RT_E_UNSUPPORTED, "scenes with volumes run on the megakernel pipeline only (use auto or mega)");
+        wavefront = false;
+    }
     if (params->precision == RT_PRECISION_F32) {
         if (!s->f32) {
             auto ds = std::make_unique<DeviceScene<float>>();

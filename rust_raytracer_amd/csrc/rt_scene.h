@@ -23,6 +23,11 @@ enum OpType : int32_t {
     OP_MESH = 6,        // arg = mesh instance idx
     OP_SKY = 7,         // arg = material idx
     OP_SUN = 8,         // arg = sun idx
+    // Volume::test (volume.rs:33-71) = two closest-hit searches over the boundary's sub-program, then the
+    // free-flight draw:   VOL_BEGIN  <boundary ops>  VOL_MID  <boundary ops again>  VOL_END
+    OP_VOL_BEGIN = 9,   // save the search state; boundary test over Interval::UNIVERSE
+    OP_VOL_MID = 10,    // no entry hit: restore, jump to `skip`; else second test over (t_enter + 0.0001, inf)
+    OP_VOL_END = 11,    // arg = volume idx: clamp to the caller's interval, draw the scattering distance
 };
 
 struct Op {
@@ -62,6 +67,13 @@ struct PlanePrim {  // plane.rs:14-27 (fields as computed by Plane::new, plane.r
 template <typename R>
 struct SunPrim {  // sun.rs:17-20
     R direction[3];
+    int32_t material;
+    int32_t _pad;
+};
+
+template <typename R>
+struct VolumeRec {  // volume.rs:15-19
+    R neg_inv_density;
     int32_t material;
     int32_t _pad;
 };
@@ -175,6 +187,7 @@ struct SceneView {
     const PlanePrim<R>* planes;
     const SunPrim<R>* suns;
     const MeshInst* meshes;
+    const VolumeRec<R>* volumes;   // megakernel only (global memory)
     const BvhNode<R>* nodes;
     const BvhNode4f* nodes4;       // 4-wide f32 nodes (wavefront mesh kernel)
     const Bounds<R>* mesh_bounds;  // per mesh instance: exact box of its triangles (object space)

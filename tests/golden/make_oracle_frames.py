@@ -24,6 +24,7 @@ CASES = {
     "perlin": ["scenes/perlin", "-w=48", "-s=16", "--seed=12"],
     "texture_test": ["scenes/texture_test", "-w=48", "-s=16", "--seed=14"],
     "texture_mix": ["tests/scenes/texture_mix", "-w=48", "-s=16", "--seed=15"],
+    "smoke": ["tests/scenes/smoke", "-w=48", "-s=16", "--seed=16"],
 }
 
 
