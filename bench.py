@@ -219,6 +219,10 @@ def main():
             "node_visits_per_ray": counters.node_visits / counters.rays,
             "tri_tests_per_ray": counters.tri_tests / counters.rays,
             "bytes_node": counters.bytes_node, "bytes_tri": counters.bytes_tri,
+            # the memory system's own limit for this access pattern (dependent fetches of random 128-B lines):
+            # tools/ubench/gather_lines on the same chip, profiles/r01/ubench_gather_lines.txt
+            "line_requests_per_s": (counters.node_visits + counters.tri_tests * counters.bytes_tri / 128.0) / n_launch / (avg_ms * 1e-3),
+            "random_line_ceiling_per_s": [59e9, 79e9],
         }
 
     cpu = None

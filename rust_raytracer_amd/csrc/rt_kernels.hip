@@ -629,6 +629,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
         if (stats) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_mesh<R, true>, 256, lds_mesh));
         else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_mesh<R, false>, 256, lds_mesh));
         if (blocks_per_cu < 1) blocks_per_cu = 1;
+        blocks_per_cu = std::min<int>(blocks_per_cu, int(env_u32("RT_WF_MESH_BLOCKS", 64)));  // experiments: occupancy scaling
     }
     const uint32_t isect_blocks = uint32_t(n_cu) * uint32_t(blocks_per_cu);
     if (split) {
