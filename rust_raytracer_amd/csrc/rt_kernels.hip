@@ -612,14 +612,14 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     if (stats) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_intersect<R, true>, 256, lds));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_intersect<R, false>, 256, lds));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
-    // Scenes whose program has exactly one mesh op use the split intersect (k_wf_prims + k_wf_mesh).
+    // Scenes whose program has exactly one mesh op use the split intersect (k_wf_prims + k_wf_mesh); scenes
+    // without any mesh need k_wf_prims alone.
     int32_t mesh_pc = -1;
-    {
-        int n_mesh_ops = 0;
-        for (size_t i = 0; i < s->compiled.ops.size(); i++)
-            if (s->compiled.ops[i].type == OP_MESH) { n_mesh_ops++; mesh_pc = int32_t(i); }
-        if (n_mesh_ops != 1 || env_u32("RT_WF_SPLIT", 1) == 0) mesh_pc = -1;
-    }
+    int n_mesh_ops = 0;
+    for (size_t i = 0; i < s->compiled.ops.size(); i++)
+        if (s->compiled.ops[i].type == OP_MESH) { n_mesh_ops++; mesh_pc = int32_t(i); }
+    if (n_mesh_ops != 1 || env_u32("RT_WF_SPLIT", 1) == 0) mesh_pc = -1;
+    const bool prims_only = n_mesh_ops == 0 && env_u32("RT_WF_SPLIT", 1) != 0;
     const bool split = mesh_pc >= 0;
     // k_wf_mesh keeps (child, entry distance) pairs: a shallow LDS part (occupancy) + a global spill part
     const int mesh_levels = int(s->compiled.max_bvh4_stack) + 1;
@@ -677,13 +677,14 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
         for (;;) {
             size_t ev = 0;
             for (uint32_t k = 0; k < check_every; k++) {
-                if (split) {
+                if (split || prims_only) {
 #define RT_LAUNCH_PRIMS(ST, L) hipLaunchKernelGGL((k_wf_prims<R, ST, L>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), lds_small + (WF_CHUNK + 4) * 4, stream, ds.view, pool, w.queue[qi], w.mesh_queue, w.d_ctr, s->d_counters, mesh_pc)
                     if (stats) { if (lds_tables) RT_LAUNCH_PRIMS(true, true); else RT_LAUNCH_PRIMS(true, false); }
                     else { if (lds_tables) RT_LAUNCH_PRIMS(false, true); else RT_LAUNCH_PRIMS(false, false); }
 #undef RT_LAUNCH_PRIMS
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
-                    if (stats)
+                    if (prims_only) { /* nothing deferred: the prims kernel is the whole closest-hit search */ }
+                    else if (stats)
                         hipLaunchKernelGGL((k_wf_mesh<R, true>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels);
                     else
                         hipLaunchKernelGGL((k_wf_mesh<R, false>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels);
@@ -847,9 +848,11 @@ int rt_render_device(const RtScene* scene, const RtCameraDesc* camera, const RtR
     uint32_t owned = owned_rows(camera->image_height, params);
     if (owned == 0) return RT_OK;
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
-    // AUTO: the wavefront scheduler when the scene has triangle meshes, the megakernel otherwise
+    // AUTO: the wavefront scheduler (since its state accesses are coalesced streams it beats the per-pixel
+    // megakernel on every scene measured, with or without meshes); RT_AUTO_MEGA_NO_MESH=1 restores the old rule
     bool has_mesh = !s->compiled.meshes.empty();
-    bool wavefront = params->pipeline == RT_PIPELINE_WAVEFRONT || (params->pipeline == RT_PIPELINE_AUTO && has_mesh);
+    bool wavefront = params->pipeline == RT_PIPELINE_WAVEFRONT ||
+                     (params->pipeline == RT_PIPELINE_AUTO && (has_mesh || env_u32("RT_AUTO_MEGA_NO_MESH", 0) == 0));
     if (params->max_depth == 0) wavefront = false;  // every sample is black (camera.rs:290): nothing to schedule
     if (!s->compiled.volumes.empty()) {
         // Volume::test draws from the path's RNG in the middle of the closest-hit search, in program order; the
