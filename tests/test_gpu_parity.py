@@ -249,6 +249,29 @@ def test_full_size_frame_row_partition_and_determinism(dev):
     assert_f64_parity(full[api.owned_rows(hs.height, q)], ref)
 
 
+def test_headline_config_rows_match_oracle(dev):
+    """BASELINE.json's headline configuration itself (cornell_dragon, 1200x1200, 1000 spp = 10 replicas x 10x10
+    strata, 871 200 triangles), three full rows of it (every 400th): the HIP path through the C ABI against the
+    oracle at the f64 bar, and the same rows cut out of a render that owns more rows (keyed RNG: a pixel's
+    samples do not depend on the partition)."""
+    ensure_dragon()
+    hs = api.HostScene(["scenes/cornell_dragon", "-w=1200", "-s=1000", "-t=10", "--seed=1"])
+    assert hs.spp == 1000 and hs.params.thread_count == 10 and hs.params.sqrt_spt == 10
+    scene = api.DeviceScene(hs.desc, 0)
+    q = hs.params.copy()
+    q.band_rows, q.n_parts, q.part = 1, 400, 123
+    rows = api.owned_rows(hs.height, q)
+    assert list(rows) == [123, 523, 923]
+    gpu = scene.render(hs.camera, q)
+    ref, st = pyoracle.render(hs.desc, hs.camera, q)
+    assert st.samples == 3 * 1200 * 1000
+    assert_f64_parity(gpu, ref)
+    q2 = hs.params.copy()
+    q2.band_rows, q2.n_parts, q2.part = 1, 200, 123   # rows 123, 323, 523, 723, 923, 1123
+    wider = scene.render(hs.camera, q2)
+    np.testing.assert_array_equal(wider[[0, 2, 4]], gpu)
+
+
 def test_emission_linearity_on_gpu(dev, tmp_path):
     base = ("@config output_width = 64\n@config aspect_ratio = 1\n@config camera_pos = 0,1,5\n@config camera_target = 0,1,0\n"
             "floor: plane 0,0,0 4,0,0 0,0,-4 (lambertian (constant 0.7,0.7,0.7))\n"
