@@ -111,10 +111,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the multi-rank path on a one-GPU box: RT_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and uses gloo
+    # (RCCL refuses two ranks on one device).  Never set by the driver; the result is then labelled in `config`.
+    one_device = os.environ.get("RT_BENCH_ONE_DEVICE", "0") == "1"
+    if one_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP render path has no CPU fallback)")
     device = torch.device("cuda", local_rank)
@@ -169,7 +177,7 @@ def main():
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -240,7 +248,8 @@ def main():
             "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": desc + (f" [DEBUG spp/{a.spp_divisor}]" if a.spp_divisor > 1 else ""),
                        "image": [hs.width, hs.height], "spp": hs.spp, "seed": a.seed,
-                       "pipeline": a.pipeline, "partition": f"{rtdist.BAND_ROWS}-row bands round-robin over {world} GPU(s)"},
+                       "pipeline": a.pipeline, "partition": f"{rtdist.BAND_ROWS}-row bands round-robin over {world} GPU(s)"
+                                    + (" [REHEARSAL: all ranks on one device, gloo]" if one_device else "")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if cpu:

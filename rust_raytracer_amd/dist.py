@@ -54,12 +54,14 @@ def gather_frame(local_rows: torch.Tensor, height: int, width: int) -> Optional[
     if world == 1:
         return local_rows
     pad_rows = max_rows(height, world)
-    send = torch.zeros((pad_rows, width, 4), dtype=local_rows.dtype, device=local_rows.device)
-    send[: local_rows.shape[0]] = local_rows
+    # gloo (CPU tests, single-GPU rehearsals of the multi-rank path) has no gather for device tensors: stage on the host
+    dev = torch.device("cpu") if dist.get_backend() == "gloo" else local_rows.device
+    send = torch.zeros((pad_rows, width, 4), dtype=local_rows.dtype, device=dev)
+    send[: local_rows.shape[0]] = local_rows.to(dev)
     if rank == 0:
         recv = [torch.empty_like(send) for _ in range(world)]
         dist.gather(send, gather_list=recv, dst=0)
-        frame = torch.empty((height, width, 4), dtype=local_rows.dtype, device=local_rows.device)
+        frame = torch.empty((height, width, 4), dtype=local_rows.dtype, device=dev)
         for r in range(world):
             rows = rows_of_part(height, world, r)
             idx = torch.as_tensor(rows, dtype=torch.long, device=frame.device)
