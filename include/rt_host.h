@@ -24,7 +24,7 @@ typedef struct RtHost RtHost;
 
 /* argv[0] is skipped like env::args().skip(1) (config.rs:81).  Flags are the
  * reference's (README.md:21-43) plus --seed=<u64>, --gpus=<n>,
- * --precision=f64|f32, --pipeline=auto|mega|wavefront (unknown keys are
+ * --precision=f64|f32, --pipeline=auto|mega|wavefront, --bvh=host|device (unknown keys are
  * ignored by the reference, config.rs:146, so these are compatible).
  * Relative scene/asset paths resolve against the current directory, as in
  * the reference (main.rs:43, golden_monkey.rs:77). */

@@ -157,8 +157,13 @@ typedef struct RtSceneDesc {
     uint32_t world_root;          /* node index of `world`  (main.rs:75 arg 1) */
     const RtTexture* textures;
     uint32_t lights_root;         /* node index of `lights` (main.rs:75 arg 2) */
-    uint32_t _pad;
+    uint32_t flags;               /* RT_SCENE_* */
 } RtSceneDesc;
+
+/* RtSceneDesc.flags */
+#define RT_SCENE_BVH_ON_DEVICE 1u /* build the mesh BVHs on the GPU (LBVH: milliseconds instead of ~0.7 s per 870k
+                                     triangles, slower traversal); default: binned SAH on the host.  The tree only
+                                     culls, so the rendered values do not depend on the builder.               */
 
 /* ---- Camera: the fields of `Camera` after init() (camera.rs:19-44,86-130) */
 typedef struct RtCameraDesc {

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import Optional, Sequence
 
 import numpy as np
@@ -20,6 +21,7 @@ RT_OK = 0
 RT_E_INVALID, RT_E_UNSUPPORTED, RT_E_DEVICE, RT_E_NOMEM = -1, -2, -3, -4
 RT_PRECISION_F64, RT_PRECISION_F32 = 0, 1
 RT_PIPELINE_AUTO, RT_PIPELINE_MEGAKERNEL, RT_PIPELINE_WAVEFRONT = 0, 1, 2
+RT_SCENE_BVH_ON_DEVICE = 1  # RtSceneDesc.flags
 
 (RT_NODE_SPHERE, RT_NODE_PLANE, RT_NODE_MESH, RT_NODE_LIST, RT_NODE_TRANSFORM, RT_NODE_BVH,
  RT_NODE_SKY, RT_NODE_SUN, RT_NODE_VOLUME, RT_NODE_NULL) = range(1, 11)
@@ -71,7 +73,7 @@ class RtSceneDesc(C.Structure):
                 ("meshes", C.POINTER(RtMesh)), ("materials", C.POINTER(RtMaterial)),
                 ("n_textures", C.c_uint32), ("world_root", C.c_uint32),
                 ("textures", C.POINTER(RtTexture)),
-                ("lights_root", C.c_uint32), ("_pad", C.c_uint32)]
+                ("lights_root", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class RtCameraDesc(C.Structure):
@@ -177,6 +179,14 @@ def load_device_lib() -> C.CDLL:
             raise FileNotFoundError(
                 f"{DEVICE_LIB_PATH} is missing — the HIP render path was not built "
                 "(run __graft_entry__.build()); refusing to fall back to any CPU path")
+        # A process that also uses PyTorch must load PyTorch's HIP runtime FIRST: the wheel bundles its own
+        # libamdhip64, and if the system copy (our dependency) is already loaded, torch then sees "No HIP GPUs".
+        # Loaded in this order, both share torch's copy.  (Pure C / C++ callers are not affected.)
+        if "torch" not in sys.modules and os.environ.get("RT_NO_TORCH_PRELOAD", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:  # PyTorch absent or broken: the library works on its own
+                pass
         lib = C.CDLL(DEVICE_LIB_PATH)
         lib.rt_device_count.argtypes = []
         lib.rt_device_count.restype = C.c_int

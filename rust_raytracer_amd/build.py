@@ -15,7 +15,7 @@ REPO_DIR = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 HOST_SRC = ["scene_builder.cpp", "obj_loader.cpp", "config.cpp", "dsl_loader.cpp", "default_scene.cpp",
             "output.cpp", "host_api.cpp", "image_loader.cpp"]
-DEVICE_SRC = ["rt_kernels.hip", "rt_compile.cpp", "rt_bvh.cpp"]
+DEVICE_SRC = ["rt_kernels.hip", "rt_bvh_device.hip", "rt_compile.cpp", "rt_bvh.cpp"]
 DEVICE_HDR = ["rt_device.h", "rt_wavefront.h", "rt_scene.h", "rt_compile.h", "rt_bvh.h"]
 
 

@@ -174,6 +174,10 @@ bool config_from_args(int argc, const char* const* argv, Config* out, std::strin
             else if (value == "mega") cfg.pipeline = RT_PIPELINE_MEGAKERNEL;
             else if (value == "wavefront") cfg.pipeline = RT_PIPELINE_WAVEFRONT;
             else { *err = "Pipeline must be auto, mega or wavefront"; return false; }
+        } else if (key == "-bvh") {  // new: where the mesh BVHs are built
+            if (value == "host") cfg.bvh_on_device = false;
+            else if (value == "device") cfg.bvh_on_device = true;
+            else { *err = "BVH builder must be host or device"; return false; }
         }
         // unknown keys: ignored (config.rs:146)
     }

@@ -44,7 +44,8 @@ int rth_load(int argc, const char* const* argv, RtHost** out) {
     // SceneConfig::merge(scene defaults, CLI) then Camera::new (scene.rs:144-150, golden_monkey.rs:35-46)
     rth::SceneConfig merged = rth::merge(host->scene.scene_config, host->config.scene);
     rth::make_camera(merged, &host->camera);
-    host->desc = host->scene.builder.finish(host->scene.world, host->scene.lights);
+    host->desc = host->scene.builder.finish(host->scene.world, host->scene.lights,
+                                            host->config.bvh_on_device ? RT_SCENE_BVH_ON_DEVICE : 0u);
 
     RtRenderParams& p = host->params;
     std::memset(&p, 0, sizeof p);

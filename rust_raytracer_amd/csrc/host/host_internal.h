@@ -33,6 +33,7 @@ struct Config {
     uint32_t gpus = 1;
     uint32_t precision = RT_PRECISION_F64;
     uint32_t pipeline = RT_PIPELINE_AUTO;
+    bool bvh_on_device = false;  // --bvh=device: RT_SCENE_BVH_ON_DEVICE
 };
 bool config_from_args(int argc, const char* const* argv, Config* out, std::string* err);  // config.rs:62-176
 

@@ -4,7 +4,7 @@
 // `camera.render(world, lights, &mut buf)` the frame comes from librt_mi355.so (rt_render).
 //
 // New, optional flags (ignored by the reference's parser, so command lines stay compatible):
-//   --seed=<u64>  --gpus=<n>  --precision=f64|f32  --pipeline=auto|mega|wavefront
+//   --seed=<u64>  --gpus=<n>  --precision=f64|f32  --pipeline=auto|mega|wavefront  --bvh=host|device
 // With --gpus=n the frame is row-tiled in interleaved 16-row bands, one host thread per GPU;
 // the tiles are assembled on the host here (bench.py shows the RCCL gather path used for the
 // multi-process launch).

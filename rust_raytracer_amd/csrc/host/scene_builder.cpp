@@ -364,7 +364,7 @@ int SceneBuilder::volume(int boundary, int material, double density) {
     return id;
 }
 
-const RtSceneDesc* SceneBuilder::finish(int world, int lights) {
+const RtSceneDesc* SceneBuilder::finish(int world, int lights, uint32_t flags) {
     child_indices_.clear();
     for (size_t i = 0; i < nodes_.size(); i++) {
         nodes_[i].first_child = uint32_t(child_indices_.size());
@@ -403,6 +403,7 @@ const RtSceneDesc* SceneBuilder::finish(int world, int lights) {
     desc_.textures = textures_.data();
     desc_.world_root = uint32_t(world);
     desc_.lights_root = uint32_t(lights);
+    desc_.flags = flags;
     return &desc_;
 }
 

@@ -62,7 +62,7 @@ public:
     size_t node_count() const { return nodes_.size(); }
 
     // Freezes the tables into an RtSceneDesc whose pointers stay valid while `this` lives.
-    const RtSceneDesc* finish(int world, int lights);
+    const RtSceneDesc* finish(int world, int lights, uint32_t flags = 0);
 
 private:
     int push_node(RtNode n);

@@ -7,6 +7,7 @@
 // equal t may resolve to a different (adjacent) triangle.
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 namespace rt {
@@ -24,6 +25,11 @@ struct BvhBuild {
 
 // positions: n_positions*3 doubles; tri_pos: n_tris*3 indices.  max_leaf in 1..8.
 BvhBuild build_bvh(const double* positions, const uint32_t* tri_pos, uint32_t n_tris, uint32_t max_leaf);
+
+// The same contract, built on the current HIP device (rt_bvh_device.hip: Morton codes, radix sort, Karras radix
+// tree, bottom-up box fit).  Returns false with `err` set on a device error.
+bool build_bvh_device(const double* positions, uint32_t n_positions, const uint32_t* tri_pos, uint32_t n_tris, uint32_t max_leaf,
+                      BvhBuild* out, std::string* err);
 
 // 4-wide collapse of a BVH2 (same leaves, same triangle order): every node holds up to four
 // children, obtained by repeatedly replacing the inner child of largest surface area by its two

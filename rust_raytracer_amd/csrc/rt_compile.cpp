@@ -29,6 +29,7 @@ struct Compiler {
     const RtSceneDesc& d;
     CompiledScene& out;
     std::string* err;
+    CompileOptions opt;
     int status = RT_OK;
     std::vector<int32_t> chain;                      // transforms enclosing the current position
     std::map<std::vector<int32_t>, int32_t> chain_ids;
@@ -153,13 +154,19 @@ struct Compiler {
         if (const char* e = std::getenv("RT_BVH_MAX_LEAF")) { int v = std::atoi(e); if (v >= 1 && v <= 8) max_leaf = uint32_t(v); }
         const bool timing = std::getenv("RT_COMPILE_DEBUG") != nullptr;
         auto t0 = std::chrono::steady_clock::now();
-        BvhBuild bvh = build_bvh(m.positions, m.tri_pos, m.n_triangles, max_leaf);
+        BvhBuild bvh;
+        if (opt.bvh_on_device) {
+            std::string berr;
+            if (!build_bvh_device(m.positions, m.n_positions, m.tri_pos, m.n_triangles, max_leaf, &bvh, &berr)) return fail(RT_E_DEVICE, berr);
+        } else {
+            bvh = build_bvh(m.positions, m.tri_pos, m.n_triangles, max_leaf);
+        }
         auto t1 = std::chrono::steady_clock::now();
         Bvh4Build bvh4 = collapse_bvh4(bvh);
         auto t2 = std::chrono::steady_clock::now();
         if (timing)
-            std::fprintf(stderr, "[rt_compile] mesh %u triangles: binned-SAH BVH2 %.0f ms (%zu nodes), 4-wide collapse %.0f ms (%zu nodes)\n",
-                         m.n_triangles, std::chrono::duration<double, std::milli>(t1 - t0).count(), bvh.nodes.size(),
+            std::fprintf(stderr, "[rt_compile] mesh %u triangles: %s BVH2 %.0f ms (%zu nodes, depth %u), 4-wide collapse %.0f ms (%zu nodes)\n",
+                         m.n_triangles, opt.bvh_on_device ? "device LBVH" : "host binned-SAH", std::chrono::duration<double, std::milli>(t1 - t0).count(), bvh.nodes.size(), bvh.max_depth,
                          std::chrono::duration<double, std::milli>(t2 - t1).count(), bvh4.nodes.size());
         *node4_base = uint32_t(out.nodes4.size());
         out.nodes4.insert(out.nodes4.end(), bvh4.nodes.begin(), bvh4.nodes.end());
@@ -512,7 +519,7 @@ struct Compiler {
 
 }  // namespace
 
-int compile_scene(const RtSceneDesc* desc, CompiledScene* out, std::string* err) {
+int compile_scene(const RtSceneDesc* desc, CompiledScene* out, std::string* err, const CompileOptions& opt) {
     if (!desc || desc->abi_version != RT_MI355_ABI_VERSION) {
         *err = "scene description missing or ABI version mismatch";
         return RT_E_INVALID;
@@ -524,7 +531,7 @@ int compile_scene(const RtSceneDesc* desc, CompiledScene* out, std::string* err)
         return RT_E_INVALID;
     }
     *out = CompiledScene{};
-    Compiler c{*desc, *out, err};
+    Compiler c{*desc, *out, err, opt};
     if (!c.compile_tables()) return c.status;
     if (!c.compile_node(desc->world_root, 0)) return c.status;
     c.chain.clear();

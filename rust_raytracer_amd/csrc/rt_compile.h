@@ -38,7 +38,11 @@ struct CompiledScene {
     uint32_t max_bvh_depth = 1;
 };
 
+struct CompileOptions {
+    bool bvh_on_device = false;  // build mesh BVHs with rt_bvh_device.hip (the HIP device must already be selected)
+};
+
 // Returns RT_OK or a negative RtStatus with `err` set.
-int compile_scene(const RtSceneDesc* desc, CompiledScene* out, std::string* err);
+int compile_scene(const RtSceneDesc* desc, CompiledScene* out, std::string* err, const CompileOptions& opt = CompileOptions());
 
 }  // namespace rt

@@ -795,9 +795,19 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
     std::unique_ptr<RtScene> s(new (std::nothrow) RtScene);
     if (!s) return set_err(RT_E_NOMEM, "out of memory");
     std::string err;
-    int st = compile_scene(desc, &s->compiled, &err);
-    if (st != RT_OK) return set_err(st, err);
+    CompileOptions opt;
+    const char* builder = std::getenv("RT_BVH_BUILDER");  // "device" / "host" override the scene's flag
+    opt.bvh_on_device = desc && (desc->flags & RT_SCENE_BVH_ON_DEVICE) != 0;
+    if (builder && !std::strcmp(builder, "device")) opt.bvh_on_device = true;
+    if (builder && !std::strcmp(builder, "host")) opt.bvh_on_device = false;
     int n = 0;
+    if (opt.bvh_on_device) {  // the device builder needs its device before the scene is compiled
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return set_err(RT_E_DEVICE, "no HIP device available");
+        if (device < 0 || device >= n) return set_err(RT_E_INVALID, "device index out of range");
+        HIP_TRY(hipSetDevice(device));
+    }
+    int st = compile_scene(desc, &s->compiled, &err, opt);
+    if (st != RT_OK) return set_err(st, err);
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return set_err(RT_E_DEVICE, "no HIP device available");
     if (device < 0 || device >= n) return set_err(RT_E_INVALID, "device index out of range");
     s->device = device;

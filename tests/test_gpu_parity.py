@@ -272,6 +272,22 @@ def test_headline_config_rows_match_oracle(dev):
     np.testing.assert_array_equal(wider[[0, 2, 4]], gpu)
 
 
+@pytest.mark.parametrize("name", ["light_test", "default", "two_meshes", "texture_test"])
+def test_device_built_bvh_renders_the_same_frame(dev, name):
+    """the mesh BVH built on the GPU (LBVH, rt_bvh_device.hip) instead of the host's binned SAH.
+    The tree only culls, so the frame is the host-built one bit for bit — and the oracle's at the f64 bar."""
+    hs = api.HostScene(SCENES[name])
+    host_built = api.DeviceScene(hs.desc, 0).render(hs.camera, hs.params)
+    hs.desc.contents.flags |= api.RT_SCENE_BVH_ON_DEVICE
+    try:
+        device_built = api.DeviceScene(hs.desc, 0).render(hs.camera, hs.params)
+    finally:
+        hs.desc.contents.flags &= ~api.RT_SCENE_BVH_ON_DEVICE
+    np.testing.assert_array_equal(device_built, host_built)
+    ref, _ = pyoracle.render(hs.desc, hs.camera, hs.params)
+    assert_f64_parity(device_built, ref)
+
+
 def test_emission_linearity_on_gpu(dev, tmp_path):
     base = ("@config output_width = 64\n@config aspect_ratio = 1\n@config camera_pos = 0,1,5\n@config camera_target = 0,1,0\n"
             "floor: plane 0,0,0 4,0,0 0,0,-4 (lambertian (constant 0.7,0.7,0.7))\n"
