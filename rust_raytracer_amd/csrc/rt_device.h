@@ -900,6 +900,9 @@ struct PathState {
 };
 
 // Shades the closest hit; returns true if the path continues with ps.ray updated.
+template <typename R, bool STATS>
+RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathState<R>& ps, const HitInfo<R>& hit, Rng& rng, LaneCounters& cnt);
+
 template <typename R, bool STATS, bool TEX = false>
 RT_DEV bool shade(const SceneView<R>& sc, const ParamsView<R>& prm, PathState<R>& ps, const Best<R>& best, Rng& rng, LaneCounters& cnt) {
     if (best.pc < 0) {  // camera.rs:331 background
@@ -907,6 +910,13 @@ RT_DEV bool shade(const SceneView<R>& sc, const ParamsView<R>& prm, PathState<R>
         return false;
     }
     const HitInfo<R> hit = resolve_hit<R, TEX>(sc, ps.ray, best);
+    return shade_hit<R, STATS>(sc, prm, ps, hit, rng, cnt);
+}
+
+// The part of shade() after the hit has been resolved (k_wf_shade calls the two halves itself, so that the
+// path's throughput / radiance / RNG are loaded only after resolve_hit: they are not live across its loops).
+template <typename R, bool STATS>
+RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathState<R>& ps, const HitInfo<R>& hit, Rng& rng, LaneCounters& cnt) {
     const MaterialRec mat = sc.materials[hit.material];
     V3<R> attenuation;
     V3<R> pdf_w;          // CosinePDF::w (the shading normal), cosine.rs:17-22

@@ -649,6 +649,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     const size_t lds_small = lds_tables ? size_t(ds.view.lay.total_bytes) : 0;
     const uint32_t check_every = env_u32("RT_WF_CHECK", 8);
     const bool tex = s->compiled.needs_tex_interpreter;
+    const size_t shade_lds_pad = env_u32("RT_WF_SHADE_LDS_PAD", 0);  // experiments: fewer resident blocks of the shade kernel
 
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
@@ -697,7 +698,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
                         hipLaunchKernelGGL((k_wf_intersect<R, false>), dim3(isect_blocks), dim3(256), lds, stream, ds.view, pool, w.queue[qi], w.d_ctr, s->d_counters, refill_min);
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 }
-#define RT_LAUNCH_SHADE(ST, L, TX) hipLaunchKernelGGL((k_wf_shade<R, ST, L, TX>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), (L ? lds_small : size_t(0)) + (2 * WF_CHUNK + 8) * 4, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters)
+#define RT_LAUNCH_SHADE(ST, L, TX) hipLaunchKernelGGL((k_wf_shade<R, ST, L, TX>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), (L ? lds_small : size_t(0)) + (2 * WF_CHUNK + 8) * 4 + shade_lds_pad, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters)
                 if (tex) {  // interpreter variant: tables from global memory (rare scenes, fewer instantiations)
                     if (stats) RT_LAUNCH_SHADE(true, false, true); else RT_LAUNCH_SHADE(false, false, true);
                 } else if (stats) { if (lds_tables) RT_LAUNCH_SHADE(true, true, false); else RT_LAUNCH_SHADE(true, false, false); }

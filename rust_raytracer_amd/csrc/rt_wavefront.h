@@ -29,8 +29,11 @@
 #define RT_MESH_WAVES 4
 #endif
 // NOTE: k_wf_shade deliberately has NO waves-per-SIMD hint: with `__launch_bounds__(256, 3)` and
-// `(256, 4)` hipcc (ROCm 7.2) produced different Dielectric results (caught by the bit-exact parity
-// tests); (256, 4) also spills 240 B/lane to scratch and is 4 % slower.
+// `(256, 4)` hipcc (ROCm 7.2) produces wrong results (first Dielectric paths, later also the sphere-field scene;
+// caught by the bit-exact parity tests) and spills (80-320 B/lane): 4-5 % slower.  Re-measured after the shade
+// split below: same outcome.  At 197 VGPRs the f64 kernel runs 2 waves/SIMD; halving that costs +41 % of its
+// time (RT_WF_SHADE_LDS_PAD experiment), so a register diet would pay — the texture walk's loops are what
+// keeps ~55 VGPRs live (without them the kernel needs 144).
 
 namespace rt {
 
@@ -811,15 +814,26 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneView<R> sc_g, CameraView<
         slot = full ? i : queue_in[i];
         PathState<R> ps;
         ps.ray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
-        ps.throughput = mk<R>(pool.tr[slot], pool.tg[slot], pool.tb[slot]);
-        ps.radiance = mk<R>(pool.lr[slot], pool.lg[slot], pool.lb[slot]);
-        ps.depth = pool.depth[slot];
         Best<R> best;
         best.t = pool.ht[slot]; best.u = pool.hu[slot]; best.v = pool.hv[slot];
         best.pc = pool.hpc[slot]; best.tri = pool.htri[slot];
+        // Resolve the hit BEFORE the rest of the path state is loaded: the compiler otherwise hoists those loads
+        // above resolve_hit's loops (texture walk, transform chain) and keeps 16 more values live across them.
+        HitInfo<R> hit{};
+        if (best.pc >= 0) hit = resolve_hit<R, TEX>(sc, ps.ray, best);
+        asm volatile("" ::: "memory");
+        ps.throughput = mk<R>(pool.tr[slot], pool.tg[slot], pool.tb[slot]);
+        ps.radiance = mk<R>(pool.lr[slot], pool.lg[slot], pool.lb[slot]);
+        ps.depth = pool.depth[slot];
         Rng rng;
         rng.s = pool.rng[slot];
-        bool cont = shade<R, STATS, TEX>(sc, prm, ps, best, rng, cnt);
+        bool cont;
+        if (best.pc < 0) {  // camera.rs:331 background
+            ps.radiance = ps.radiance + ps.throughput * ld3(prm.background);
+            cont = false;
+        } else {
+            cont = shade_hit<R, STATS>(sc, prm, ps, hit, rng, cnt);
+        }
         ps.depth--;
         if (cont && ps.depth != 0) {  // depth == 0: ray_color returns black without tracing (camera.rs:290)
             pool.ox[slot] = ps.ray.o.x; pool.oy[slot] = ps.ray.o.y; pool.oz[slot] = ps.ray.o.z;
