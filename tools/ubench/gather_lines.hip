@@ -95,10 +95,15 @@ double run(const float4* table, uint32_t n_lines, int blocks_per_cu, uint32_t it
     return lines / (ms * 1e-3);
 }
 
-int main() {
-    const size_t sizes_mb[] = {2, 17, 87, 220, 1024};
+int main(int argc, char** argv) {
+    const bool calib = argc > 1;  // `gather_lines calib`: two tables, one kernel each (for a PMC pass with known byte counts)
+    const size_t sizes_all[] = {2, 17, 87, 220, 1024};
+    const size_t sizes_calib[] = {87, 1024};
+    const size_t* sizes_mb = calib ? sizes_calib : sizes_all;
+    const size_t n_sizes = calib ? 2 : 5;
     float* out; CHECK(hipMalloc(&out, 4));
-    for (size_t mb : sizes_mb) {
+    for (size_t si = 0; si < n_sizes; si++) {
+        const size_t mb = sizes_mb[si];
         size_t bytes = mb << 20;
         uint32_t n_lines = uint32_t(bytes / 128);
         float4* table; CHECK(hipMalloc(&table, bytes));
@@ -106,6 +111,12 @@ int main() {
         uint32_t s = 1u;
         for (auto& v : h) { s = s * 1664525u + 1013904223u; v = s; }
         CHECK(hipMemcpy(table, h.data(), bytes, hipMemcpyHostToDevice));
+        if (calib) {
+            double b = run<0, true>(table, n_lines, 4, 800, out);
+            std::printf("calib: table %zu MB, lane shape, dependent: warm-up launch 100 iterations then 800 iterations x %d threads x 128 B = %.3f GB: %.1f G lines/s\n", mb, 256 * 4 * 256, 256.0 * 4 * 256 * 800 * 128 / 1e9, b / 1e9);
+            CHECK(hipFree(table));
+            continue;
+        }
         for (int bpc : {4, 8}) {
             double a = run<0, false>(table, n_lines, bpc, 2000, out);
             double b = run<0, true>(table, n_lines, bpc, 2000, out);
