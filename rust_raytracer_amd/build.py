@@ -94,6 +94,11 @@ def build_tools(force: bool = False) -> str:
     src = os.path.join(REPO_DIR, "tools", "gen_dragon.cpp")
     if os.path.exists(src) and (force or _newer(out, [src])):
         _run(["g++", "-std=c++17", "-O2", "-o", out, src])
+    # micro-benchmark that pins the traversal kernel's roofline (random-line gather rates)
+    ub_src = os.path.join(REPO_DIR, "tools", "ubench", "gather_lines.hip")
+    ub_out = os.path.join(REPO_DIR, "tools", "ubench", "gather_lines")
+    if os.path.exists(ub_src) and (force or _newer(ub_out, [ub_src])):
+        _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-o", ub_out, ub_src])
     return out
 
 
