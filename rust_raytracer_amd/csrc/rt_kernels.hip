@@ -587,6 +587,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     if (budget > avail / 2) budget = avail / 2;
     uint64_t bytes_per_replica = per_replica * 24ull;
     uint32_t group = uint32_t(std::min<uint64_t>(T, std::max<uint64_t>(1, budget / bytes_per_replica)));
+    group = (T + (T + group - 1) / group - 1) / ((T + group - 1) / group);  // same number of groups, equal sizes (9 + 1 -> 5 + 5)
     if (bytes_per_replica > avail) return set_err(RT_E_NOMEM, "per-sample radiance buffer of one replica does not fit in device memory");
     size_t need = size_t(bytes_per_replica) * group;
     if (w.sample_L_bytes < need) {
