@@ -216,10 +216,11 @@ def main():
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel": "k_megakernel" if mega else "k_wf_mesh (BVH traversal; k_wf_intersect for scenes with != 1 mesh)",
-            "note": "algorithmic bytes / kernel time; the BVH4 nodes (17 MB) and most triangle records are served by L2 "
-                    "(47 % hits) and the 256 MB Infinity Cache, so this is above what HBM itself moves; `traffic` = rocprofv3 "
-                    "FETCH_SIZE+WRITE_SIZE (fabric side, raw) of the same kernel per launch (profiles/r01); the kernel is "
-                    "VALU-issue bound (54 % busy) rather than memory bound",
+            "note": "algorithmic bytes / kernel time; part of these bytes is served by L2 (29 % hits) and the 256 MB Infinity "
+                    "Cache, so this is above what HBM itself moves; `traffic` = rocprofv3 FETCH_SIZE+WRITE_SIZE (fabric side, raw) of "
+                    "the same kernel per launch (profiles/r01). The kernel's real limit is the REQUEST rate of the L2-miss path: "
+                    "58.8 G L1->L2 read requests/s measured (TCP_TCC_READ_REQ) against 59-79 G/s that a pure random-line gather "
+                    "reaches on this chip (tools/ubench/gather_lines)",
             "dominant_kernel_share_of_step": (avg_ms * n_launch) / (elapsed / a.steps * 1e3),
             "kernel_ms_avg": avg_ms, "launches_per_step": n_launch, "algorithmic_bytes_per_launch": nbytes,
             "kernel_ms_per_step": avg_ms * n_launch,
