@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 
 #include "rt_scene.h"
@@ -10,7 +11,8 @@
 namespace rt {
 namespace {
 
-constexpr int kBins = 16;
+constexpr int kMaxBins = 64;
+static int g_bins = 16;  // RT_BVH_BINS (experiments)
 constexpr double kInf = std::numeric_limits<double>::infinity();
 
 struct Box {
@@ -62,8 +64,9 @@ struct Builder {
         for (int a = 0; a < 3; a++) {
             double ext = cbox.hi[a] - cbox.lo[a];
             if (!(ext > 0.0) || !std::isfinite(ext)) continue;
-            Box bins[kBins];
-            uint32_t counts[kBins] = {0};
+            const int kBins = g_bins;
+            Box bins[kMaxBins];
+            uint32_t counts[kMaxBins] = {0};
             double scale = double(kBins) / ext;
             for (uint32_t i = begin; i < end; i++) {
                 int b = int((centroid[3 * order[i] + a] - cbox.lo[a]) * scale);
@@ -72,8 +75,8 @@ struct Builder {
                 bins[b].grow(tri_box[order[i]]);
                 counts[b]++;
             }
-            double right_area[kBins];
-            uint32_t right_count[kBins];
+            double right_area[kMaxBins];
+            uint32_t right_count[kMaxBins];
             Box acc;
             uint32_t cnt = 0;
             for (int b = kBins - 1; b > 0; b--) {
@@ -100,6 +103,7 @@ struct Builder {
         if (best_axis < 0) {
             mid = begin + n / 2;  // all centroids coincide (or non-finite): split by index
         } else {
+            const int kBins = g_bins;
             double ext = cbox.hi[best_axis] - cbox.lo[best_axis];
             double scale = double(kBins) / ext;
             double lo = cbox.lo[best_axis];
@@ -132,6 +136,7 @@ struct Builder {
 }  // namespace
 
 BvhBuild build_bvh(const double* positions, const uint32_t* tri_pos, uint32_t n_tris, uint32_t max_leaf) {
+    if (const char* e = std::getenv("RT_BVH_BINS")) { int v = std::atoi(e); if (v >= 2 && v <= kMaxBins) g_bins = v; }
     Builder b;
     b.max_leaf = std::min<uint32_t>(std::max<uint32_t>(max_leaf, 1), 8);
     b.tri_box.resize(n_tris);
