@@ -648,7 +648,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     // small tables staged in LDS by the prims / shade kernels when they fit
     const bool lds_tables = ds.view.lay.total_bytes <= 48u * 1024u && env_u32("RT_LDS_TABLES", 1) != 0;
     const size_t lds_small = lds_tables ? size_t(ds.view.lay.total_bytes) : 0;
-    const uint32_t check_every = env_u32("RT_WF_CHECK", 8);
+    const uint32_t check_every = std::min<uint32_t>(32u, std::max<uint32_t>(1u, env_u32("RT_WF_CHECK", 8)));  // 2 timing events per iteration, 64 events
     const bool tex = s->compiled.needs_tex_interpreter;
     const size_t shade_lds_pad = env_u32("RT_WF_SHADE_LDS_PAD", 0);  // experiments: fewer resident blocks of the shade kernel
 
