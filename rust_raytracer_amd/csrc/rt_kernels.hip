@@ -610,8 +610,9 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     int n_cu = 0, blocks_per_cu = 0;
     HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->device));
     const bool stats = p.collect_stats != 0;
-    if (stats) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_intersect<R, true>, 256, lds));
-    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_intersect<R, false>, 256, lds));
+    const bool vol = !s->compiled.volumes.empty();  // volume ops: combined intersect kernel, VOL variant
+    if (vol) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_intersect<R, false, true>, 256, lds));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_intersect<R, false, false>, 256, lds));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     // Scenes whose program has exactly one mesh op use the split intersect (k_wf_prims + k_wf_mesh); scenes
     // without any mesh need k_wf_prims alone.
@@ -619,8 +620,8 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     int n_mesh_ops = 0;
     for (size_t i = 0; i < s->compiled.ops.size(); i++)
         if (s->compiled.ops[i].type == OP_MESH) { n_mesh_ops++; mesh_pc = int32_t(i); }
-    if (n_mesh_ops != 1 || env_u32("RT_WF_SPLIT", 1) == 0) mesh_pc = -1;
-    const bool prims_only = n_mesh_ops == 0 && env_u32("RT_WF_SPLIT", 1) != 0;
+    if (n_mesh_ops != 1 || env_u32("RT_WF_SPLIT", 1) == 0 || vol) mesh_pc = -1;  // a volume's draws happen in program order
+    const bool prims_only = n_mesh_ops == 0 && env_u32("RT_WF_SPLIT", 1) != 0 && !vol;
     const bool split = mesh_pc >= 0;
     // k_wf_mesh keeps (child, entry distance) pairs: a shallow LDS part (occupancy) + a global spill part
     const int mesh_levels = int(s->compiled.max_bvh4_stack) + 1;
@@ -693,10 +694,10 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 } else {
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
-                    if (stats)
-                        hipLaunchKernelGGL((k_wf_intersect<R, true>), dim3(isect_blocks), dim3(256), lds, stream, ds.view, pool, w.queue[qi], w.d_ctr, s->d_counters, refill_min);
-                    else
-                        hipLaunchKernelGGL((k_wf_intersect<R, false>), dim3(isect_blocks), dim3(256), lds, stream, ds.view, pool, w.queue[qi], w.d_ctr, s->d_counters, refill_min);
+#define RT_LAUNCH_ISECT(ST, VL) hipLaunchKernelGGL((k_wf_intersect<R, ST, VL>), dim3(isect_blocks), dim3(256), lds, stream, ds.view, pool, w.queue[qi], w.d_ctr, s->d_counters, refill_min)
+                    if (stats) { if (vol) RT_LAUNCH_ISECT(true, true); else RT_LAUNCH_ISECT(true, false); }
+                    else { if (vol) RT_LAUNCH_ISECT(false, true); else RT_LAUNCH_ISECT(false, false); }
+#undef RT_LAUNCH_ISECT
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 }
 #define RT_LAUNCH_SHADE(ST, L, TX) hipLaunchKernelGGL((k_wf_shade<R, ST, L, TX>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), (L ? lds_small : size_t(0)) + (2 * WF_CHUNK + 8) * 4 + shade_lds_pad, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters)
@@ -866,13 +867,6 @@ int rt_render_device(const RtScene* scene, const RtCameraDesc* camera, const RtR
     bool wavefront = params->pipeline == RT_PIPELINE_WAVEFRONT ||
                      (params->pipeline == RT_PIPELINE_AUTO && (has_mesh || env_u32("RT_AUTO_MEGA_NO_MESH", 0) == 0));
     if (params->max_depth == 0) wavefront = false;  // every sample is black (camera.rs:290): nothing to schedule
-    if (!s->compiled.volumes.empty()) {
-        // Volume::test draws from the path's RNG in the middle of the closest-hit search, in program order; the
-        // wavefront scheduler splits that search over kernels.  Volumes therefore run on the megakernel.
-        if (params->pipeline == RT_PIPELINE_WAVEFRONT)
-            return set_err(RT_E_UNSUPPORTED, "scenes with volumes run on the megakernel pipeline only (use auto or mega)");
-        wavefront = false;
-    }
     if (params->precision == RT_PRECISION_F32) {
         if (!s->f32) {
             auto ds = std::make_unique<DeviceScene<float>>();

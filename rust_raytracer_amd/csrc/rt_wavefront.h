@@ -161,14 +161,21 @@ RT_DEV bool wave_fetch(WaveRange& r, unsigned long long idle, uint32_t* cursor, 
 // Intersect: world.test for every queued path.  Persistent waves; each lane is a small state
 // machine (scene program counter + BVH traversal state), idle lanes are refilled from the queue.
 // ---------------------------------------------------------------------------------------------
-template <typename R, bool STATS>
+// VOL: the program contains volume ops (OP_VOL_*): the search then carries the path's RNG (Volume::test draws the
+// free-flight distance in the middle of it, volume.rs:47) and a second search state for the boundary tests.
+template <typename R, bool STATS, bool VOL>
 __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<R> sc, WfPool<R> pool, const uint32_t* __restrict__ queue,
                                                       WfCounters* __restrict__ ctr, DeviceCounters* counters, uint32_t refill_min) {
     extern __shared__ int lds_stack[];
     int* stack = lds_stack + threadIdx.x;
     const int stride = int(blockDim.x);
     const uint32_t n = ctr->n_in;
-    const R t_lo = R(0.001);
+    const R t_lo_outer = R(0.001);
+    R t_lo = t_lo_outer;     // changes only inside a volume's boundary searches
+    Best<R> saved{};         // VOL: the caller's search state during a boundary search
+    R vol_enter = R(0);
+    Rng rng;
+    rng.s = 0;
 
     LaneCounters cnt;
     bool has = false;        // this lane holds a ray
@@ -202,6 +209,7 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<
                 pc = 0;
                 has = true;
                 in_mesh = false;
+                if constexpr (VOL) { rng.s = pool.rng[slot]; t_lo = t_lo_outer; }
                 if (STATS) cnt.rays++;
             }
         }
@@ -216,6 +224,7 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<
                 if (op.type == OP_END) {
                     pool.ht[slot] = best.t; pool.hu[slot] = best.u; pool.hv[slot] = best.v;
                     pool.hpc[slot] = best.pc; pool.htri[slot] = best.tri;
+                    if constexpr (VOL) pool.rng[slot] = rng.s;
                     has = false;
                     break;
                 }
@@ -237,6 +246,54 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<
                     break;
                 }
                 switch (op.type) {
+                    case OP_VOL_BEGIN:  // volume.rs:34: boundary.test(ray, Interval::UNIVERSE)
+                        if constexpr (VOL) {
+                            saved = best;
+                            best.t = Lim<R>::inf();
+                            best.pc = -1;
+                            t_lo = -Lim<R>::inf();
+                        }
+                        break;
+                    case OP_VOL_MID:  // volume.rs:35-37: second search over (t_enter + 0.0001, inf)
+                        if constexpr (VOL) {
+                            if (best.pc < 0) {
+                                best = saved;
+                                t_lo = t_lo_outer;
+                                pc = op.skip;
+                                continue;
+                            }
+                            vol_enter = best.t;
+                            t_lo = vol_enter + R(0.0001);
+                            best.t = Lim<R>::inf();
+                            best.pc = -1;
+                        }
+                        break;
+                    case OP_VOL_END:  // volume.rs:38-68
+                        if constexpr (VOL) {
+                            const bool has_exit = best.pc >= 0;
+                            const R t_exit = best.t;
+                            best = saved;
+                            t_lo = t_lo_outer;
+                            if (has_exit) {
+                                R t_min = fmax(vol_enter, t_lo_outer);
+                                R t_max = fmin(t_exit, best.t);
+                                if (!(t_min >= t_max)) {
+                                    t_min = fmax(t_min, R(0));
+                                    R ray_len = length(cur.d);
+                                    R dist_inside = (t_max - t_min) * ray_len;
+                                    R uu = rng_uniform<R>(rng);
+                                    R hit_dist = sc.volumes[op.arg].neg_inv_density * (uu == R(0) ? -Lim<R>::inf() : log_r(uu));
+                                    if (!(hit_dist > dist_inside)) {
+                                        best.t = t_min + hit_dist / ray_len;
+                                        best.pc = pc;
+                                        best.tri = -1;
+                                        best.u = R(0);
+                                        best.v = R(0);
+                                    }
+                                }
+                            }
+                        }
+                        break;
                     case OP_BOUNDS:
                         if (!test_bounding_box(sc.bounds[op.arg], cur, t_lo, best.t)) {
                             pc = op.skip;

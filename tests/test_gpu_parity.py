@@ -41,10 +41,9 @@ SCENES = {
     "earth": ["scenes/earth", "-w=48", "-s=16", "--seed=13"],          # JPEG texture on a sphere
     "texture_test": ["scenes/texture_test", "-w=48", "-s=16", "--seed=14"],  # PNG albedo / roughness channel / normal map on a mesh
     "texture_mix": ["tests/scenes/texture_mix", "-w=48", "-s=16", "--seed=15"],  # every operator, every primitive's tangent frame
-    # constant-density volumes (sphere / mesh / box boundaries): megakernel pipeline only
+    # constant-density volumes (sphere / mesh / box boundaries); wavefront: combined intersect kernel, VOL variant
     "smoke": ["tests/scenes/smoke", "-w=48", "-s=16", "--seed=16"],
 }
-MEGA_ONLY = {"smoke"}
 
 
 @pytest.fixture(scope="module")
@@ -76,15 +75,6 @@ def test_f64_matches_oracle(dev, name, pipeline):
     scene = api.DeviceScene(hs.desc, 0)
     p = hs.params.copy()
     p.pipeline = PIPELINES[pipeline]
-    if name in MEGA_ONLY and pipeline == "wavefront":
-        # Volume::test draws from the path RNG in the middle of the closest-hit search: not split over kernels
-        with pytest.raises(api.RtError) as e:
-            scene.render(hs.camera, p)
-        assert e.value.status == api.RT_E_UNSUPPORTED
-        p.pipeline = api.RT_PIPELINE_AUTO          # auto falls back to the megakernel
-        scene.render(hs.camera, p)
-        assert scene.stats().pipeline_used == api.RT_PIPELINE_MEGAKERNEL
-        return
     ref, _ = pyoracle.render(hs.desc, hs.camera, hs.params)
     gpu = scene.render(hs.camera, p)
     assert gpu.shape == ref.shape
@@ -131,7 +121,7 @@ def test_f32_is_statistically_equivalent(dev, name):
     assert close.mean() >= 0.95, f"only {close.mean():.3%} of f32 values are close to the f64 oracle"
 
 
-@pytest.mark.parametrize("name", ["cornell", "hollow_glass", "default", "light_test", "two_meshes", "texture_mix"])
+@pytest.mark.parametrize("name", ["cornell", "hollow_glass", "default", "light_test", "two_meshes", "texture_mix", "smoke"])
 def test_every_kernel_variant_is_bit_identical(dev, name, monkeypatch):
     """The wavefront kernels exist in several template variants (counters on/off, small tables in
     LDS or global memory, split or combined intersect).  hipcc (ROCm 7.2) has produced wrong Dielectric
