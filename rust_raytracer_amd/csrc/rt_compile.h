@@ -19,7 +19,7 @@ struct CompiledScene {
     std::vector<PlanePrim<double>> planes;
     std::vector<SunPrim<double>> suns;
     std::vector<MeshInst> meshes;
-    std::vector<VolumeRec<double>> volumes;  // OP_VOL_* (megakernel pipeline only)
+    std::vector<VolumeRec<double>> volumes;  // OP_VOL_* (world_test<VOL> / k_wf_intersect<VOL>)
     std::vector<BuildNode> nodes;            // all meshes, node indices relative to MeshInst::node_base
     std::vector<BuildNode4> nodes4;          // 4-wide collapse, relative to MeshInst::node4_base
     std::vector<Bounds<double>> mesh_bounds; // per MeshInst

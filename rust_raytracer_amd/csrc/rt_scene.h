@@ -187,7 +187,7 @@ struct SceneView {
     const PlanePrim<R>* planes;
     const SunPrim<R>* suns;
     const MeshInst* meshes;
-    const VolumeRec<R>* volumes;   // megakernel only (global memory)
+    const VolumeRec<R>* volumes;   // global memory (not in the LDS blob)
     const BvhNode<R>* nodes;
     const BvhNode4f* nodes4;       // 4-wide f32 nodes (wavefront mesh kernel)
     const Bounds<R>* mesh_bounds;  // per mesh instance: exact box of its triangles (object space)
