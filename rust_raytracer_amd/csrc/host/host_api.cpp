@@ -29,9 +29,11 @@ int rth_load(int argc, const char* const* argv, RtHost** out) {
         if (!rth::load_default_scene(rng, &host->scene, &host->log, &err)) return fail(err);
     } else if (scene == "earth" || scene == "perlin" || scene == "light_test" || scene == "cornell" ||
                scene == "cornell_smoke" || scene == "tonemap_test") {
-        // main.rs:32-37: hard-coded Rust scenes other than the default one are scene *data*
-        // outside the render path; their DSL twins under scenes/ are supported.
-        return fail("built-in scene '" + scene + "' is not compiled in; use the DSL file scenes/" + scene);
+        // main.rs:32-37: the reference's other hard-coded Rust scenes are scene DATA outside the render path; here the
+        // names select their DSL twins (scenes/<name>, relative to the current directory like every asset path).
+        const std::string path = "scenes/" + scene;
+        if (!rth::load_dsl_scene(path, "scenes/", rng, &host->scene, &host->log, &err))
+            return fail("built-in scene '" + scene + "' is provided as the DSL file " + path + ": " + err);
     } else if (scene.rfind("model:", 0) == 0) {
         return fail("model: loader (Assimp) is not available");  // main.rs:38-41, out of scope
     } else {

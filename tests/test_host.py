@@ -149,6 +149,24 @@ def test_dsl_aspect_ratio_division_and_inline():
 
 
 # ---------------------------------------------------------------- loaders/obj.rs
+def test_builtin_scene_names_select_the_dsl_twins(repo_dir):
+    """main.rs:31-37: a bare scene name selects a built-in scene; here the names map to the DSL twins under
+    scenes/ (cornell_smoke is a DSL transcription of src/scene/cornell_smoke.rs: 6 quads + 2 volumes)."""
+    cwd = os.getcwd()
+    os.chdir(repo_dir)
+    try:
+        hs = scene("cornell_smoke", "-w=32", "-s=1")
+        d = hs.desc.contents
+        kinds = [d.nodes[i].type for i in range(d.n_nodes)]
+        assert kinds.count(api.RT_NODE_VOLUME) == 2 and kinds.count(api.RT_NODE_PLANE) == 6 + 12
+        assert hs.width == 32 and hs.height == 32
+        by_name = scene("cornell", "-w=32", "-s=1")
+        by_path = scene("scenes/cornell", "-w=32", "-s=1")
+        assert by_name.desc.contents.n_nodes == by_path.desc.contents.n_nodes
+    finally:
+        os.chdir(cwd)
+
+
 def test_obj_loader_counts_and_normalisation():
     hs = scene("scenes/light_test")
     assert "Loaded 15744 tris" in hs.log                     # obj.rs:99
