@@ -91,8 +91,8 @@ def cpu_baseline(workload: str, seed: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
     ap.add_argument("--pipeline", default="auto", choices=["auto", "mega", "wavefront"])
