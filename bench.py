@@ -156,7 +156,7 @@ def main():
     # Warmup; the first warmup step also collects the traversal counters (deterministic for a
     # given seed/config) that turn kernel time into algorithmic bytes.
     counters = None
-    for i in range(a.warmup):
+    for i in range(max(a.warmup, 1)):  # --warmup 0 still gets the one untimed counter-collecting step
         step(collect_stats=(i == 0))
         if i == 0:
             counters = scene.stats()
