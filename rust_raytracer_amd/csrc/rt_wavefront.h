@@ -718,8 +718,10 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
                 const float nza[4] = {nz.x, nz.y, nz.z, nz.w}, fza[4] = {fz.x, fz.y, fz.z, fz.w};
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    float tn = fmaxf(fmaxf(nxa[k] * ivx - oix, nya[k] * ivy - oiy), fmaxf(nza[k] * ivz - oiz, 0.0f));
-                    float tf = fminf(fminf(fxa[k] * ivx - oix, fya[k] * ivy - oiy), fminf(fza[k] * ivz - oiz, tmax32));
+                    // explicit FMAs: the translation unit is built with -ffp-contract=off for the f64 parity arithmetic, but
+                    // this f32 test only culls (its rounding is inside the boxes' padding either way): 24 fewer instructions
+                    float tn = fmaxf(fmaxf(fmaf(nxa[k], ivx, -oix), fmaf(nya[k], ivy, -oiy)), fmaxf(fmaf(nza[k], ivz, -oiz), 0.0f));
+                    float tf = fminf(fminf(fmaf(fxa[k], ivx, -oix), fmaf(fya[k], ivy, -oiy)), fminf(fmaf(fza[k], ivz, -oiz), tmax32));
                     bool h = (tn <= tf) && ch[k] != kEmptyChild;
                     nr[k] = h ? tn : __builtin_huge_valf();
                 }
