@@ -484,21 +484,46 @@ struct Compiler {
         return true;
     }
 
-    bool add_light(uint32_t node) {
+    // One entry of the light table for `node`.  nested: the node is a member of an ObjectList inside `lights`.
+    bool light_of(uint32_t node, bool nested, LightRec* l) {
         if (node >= d.n_nodes) return fail(RT_E_INVALID, "light node index out of range");
         const RtNode& n = d.nodes[node];
-        LightRec l{LIGHT_OTHER, 0};
+        *l = LightRec{LIGHT_OTHER, 0};
         switch (n.type) {
-            case RT_NODE_PLANE: l.kind = LIGHT_PLANE; l.index = plane_index(node); break;
-            case RT_NODE_SPHERE: l.kind = LIGHT_SPHERE; l.index = sphere_index(node); break;
-            case RT_NODE_SKY: l.kind = LIGHT_SKY; break;
-            case RT_NODE_SUN: l.kind = LIGHT_SUN; l.index = sun_index(node); break;
+            case RT_NODE_PLANE: l->kind = LIGHT_PLANE; l->index = plane_index(node); break;
+            case RT_NODE_SPHERE: l->kind = LIGHT_SPHERE; l->index = sphere_index(node); break;
+            case RT_NODE_SKY: l->kind = LIGHT_SKY; break;
+            case RT_NODE_SUN: l->kind = LIGHT_SUN; l->index = sun_index(node); break;
             case RT_NODE_LIST:
-                return fail(RT_E_UNSUPPORTED, "nested lists inside `lights` are not supported by the HIP kernels yet");
+                if (nested) return fail(RT_E_UNSUPPORTED, "lists nested more than one level inside `lights` are not supported");
+                l->kind = LIGHT_LIST;
+                break;
             default: break;  // Transform / mesh / bvh / volume / null: pdf_value 0, random (1,0,0)
         }
-        if (l.index < 0) return false;
-        out.lights.push_back(l);
+        return l->index >= 0;
+    }
+
+    bool compile_light_entries(const uint32_t* nodes, uint32_t count) {
+        // top-level entries first (lights_pdf_value / lights_random index them directly), members of nested lists behind
+        const size_t base = out.lights.size();
+        for (uint32_t k = 0; k < count; k++) {
+            LightRec l;
+            if (!light_of(nodes[k], false, &l)) return false;
+            out.lights.push_back(l);
+        }
+        for (uint32_t k = 0; k < count; k++) {
+            if (out.lights[base + k].kind != LIGHT_LIST) continue;
+            const RtNode& n = d.nodes[nodes[k]];
+            if (uint64_t(n.first_child) + n.n_children > d.n_child_indices) return fail(RT_E_INVALID, "child range out of bounds");
+            if (out.lights.size() >= (1u << kLightListShift) || n.n_children >= (1u << 11)) return fail(RT_E_UNSUPPORTED, "light list too large");
+            out.lights[base + k].index = int32_t(out.lights.size() | (size_t(n.n_children) << kLightListShift));
+            out.needs_tex_interpreter = true;  // the full-feature kernel variants evaluate nested light lists
+            for (uint32_t j = 0; j < n.n_children; j++) {
+                LightRec l;
+                if (!light_of(d.child_indices[n.first_child + j], true, &l)) return false;
+                out.lights.push_back(l);
+            }
+        }
         return true;
     }
 
@@ -508,12 +533,13 @@ struct Compiler {
         if (n.type == RT_NODE_LIST) {
             out.lights_is_list = 1;
             if (uint64_t(n.first_child) + n.n_children > d.n_child_indices) return fail(RT_E_INVALID, "child range out of bounds");
-            for (uint32_t k = 0; k < n.n_children; k++)
-                if (!add_light(d.child_indices[n.first_child + k])) return false;
-            return true;
+            out.n_top_lights = int32_t(n.n_children);
+            return compile_light_entries(d.child_indices + n.first_child, n.n_children);
         }
         out.lights_is_list = 0;
-        return add_light(d.lights_root);
+        out.n_top_lights = 1;
+        uint32_t root = d.lights_root;
+        return compile_light_entries(&root, 1);
     }
 };
 

@@ -35,6 +35,7 @@ struct CompiledScene {
     std::vector<LightRec> lights;
     bool needs_tex_interpreter = false;        // any lerp / image / noise / channel op or normal map
     int32_t lights_is_list = 0;
+    int32_t n_top_lights = 0;                  // entries of `lights` itself (members of nested lists follow in `lights`)
     uint32_t max_bvh_depth = 1;
 };
 

@@ -820,12 +820,24 @@ template <typename R, bool STATS> RT_DEV R light_pdf_value(const SceneView<R>& s
         default: return R(0);                             // Transform / mesh / bvh / volume
     }
 }
+// A member of `lights` that is itself an ObjectList (FULL kernel variants only): list.rs:80-89 once more
+template <typename R, bool STATS> RT_DEV R light_list_pdf_value(const SceneView<R>& sc, const LightRec& l, V3<R> origin, V3<R> dir, LaneCounters& cnt) {
+    const int32_t first = l.index & ((1 << kLightListShift) - 1), count = l.index >> kLightListShift;
+    R weight = R(1) / R(count);
+    R sum = R(0);
+    for (int32_t j = 0; j < count; j++) sum += weight * light_pdf_value<R, STATS>(sc, sc.lights[first + j], origin, dir, cnt);
+    return sum;
+}
 // lights.pdf_value(origin, dir): ObjectList (list.rs:80-89) or the single object
-template <typename R, bool STATS> RT_DEV R lights_pdf_value(const SceneView<R>& sc, V3<R> origin, V3<R> dir, LaneCounters& cnt) {
+template <typename R, bool STATS, bool FULL> RT_DEV R lights_pdf_value(const SceneView<R>& sc, V3<R> origin, V3<R> dir, LaneCounters& cnt) {
     if (!sc.lights_is_list) return light_pdf_value<R, STATS>(sc, sc.lights[0], origin, dir, cnt);
     R weight = R(1) / R(sc.n_lights);
     R sum = R(0);
-    for (int32_t i = 0; i < sc.n_lights; i++) sum += weight * light_pdf_value<R, STATS>(sc, sc.lights[i], origin, dir, cnt);
+    for (int32_t i = 0; i < sc.n_lights; i++) {
+        const LightRec l = sc.lights[i];
+        if (FULL && l.kind == LIGHT_LIST) sum += weight * light_list_pdf_value<R, STATS>(sc, l, origin, dir, cnt);
+        else sum += weight * light_pdf_value<R, STATS>(sc, l, origin, dir, cnt);
+    }
     return sum;
 }
 template <typename R> RT_DEV V3<R> light_random(const SceneView<R>& sc, const LightRec& l, V3<R> origin, Rng& rng) {
@@ -859,11 +871,17 @@ template <typename R> RT_DEV V3<R> light_random(const SceneView<R>& sc, const Li
         default: return mk<R>(1, 0, 0);
     }
 }
-template <typename R> RT_DEV V3<R> lights_random(const SceneView<R>& sc, V3<R> origin, Rng& rng) {
+template <typename R, bool FULL> RT_DEV V3<R> lights_random(const SceneView<R>& sc, V3<R> origin, Rng& rng) {
     if (!sc.lights_is_list) return light_random(sc, sc.lights[0], origin, rng);
     if (sc.n_lights == 0) return mk<R>(1, 0, 0);  // list.rs:93-95
     uint32_t idx = rng.below(uint32_t(sc.n_lights));
-    return light_random(sc, sc.lights[idx], origin, rng);
+    LightRec l = sc.lights[idx];
+    if (FULL && l.kind == LIGHT_LIST) {  // the member is an ObjectList: list.rs:91-100 once more
+        const int32_t first = l.index & ((1 << kLightListShift) - 1), count = l.index >> kLightListShift;
+        if (count == 0) return mk<R>(1, 0, 0);
+        l = sc.lights[first + int32_t(rng.below(uint32_t(count)))];
+    }
+    return light_random(sc, l, origin, rng);
 }
 
 // ------------------------------------------------------------------ camera.rs:260-280, 334-349
@@ -900,7 +918,7 @@ struct PathState {
 };
 
 // Shades the closest hit; returns true if the path continues with ps.ray updated.
-template <typename R, bool STATS>
+template <typename R, bool STATS, bool FULL>
 RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathState<R>& ps, const HitInfo<R>& hit, Rng& rng, LaneCounters& cnt);
 
 template <typename R, bool STATS, bool TEX = false>
@@ -910,12 +928,13 @@ RT_DEV bool shade(const SceneView<R>& sc, const ParamsView<R>& prm, PathState<R>
         return false;
     }
     const HitInfo<R> hit = resolve_hit<R, TEX>(sc, ps.ray, best);
-    return shade_hit<R, STATS>(sc, prm, ps, hit, rng, cnt);
+    return shade_hit<R, STATS, TEX>(sc, prm, ps, hit, rng, cnt);
 }
 
 // The part of shade() after the hit has been resolved (k_wf_shade calls the two halves itself, so that the
 // path's throughput / radiance / RNG are loaded only after resolve_hit: they are not live across its loops).
-template <typename R, bool STATS>
+// FULL: the full-feature kernel variant (TEX): additionally evaluates ObjectLists nested inside `lights`.
+template <typename R, bool STATS, bool FULL>
 RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathState<R>& ps, const HitInfo<R>& hit, Rng& rng, LaneCounters& cnt) {
     const MaterialRec mat = sc.materials[hit.material];
     V3<R> attenuation;
@@ -987,7 +1006,7 @@ RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathStat
     // ScatteredWithPDF: camera.rs:298-315 with MixPDF (mix.rs:23-36)
     V3<R> dir;
     if (rng_uniform<R>(rng) < prm.light_bias) {
-        dir = lights_random(sc, hit.pos, rng);
+        dir = lights_random<R, FULL>(sc, hit.pos, rng);
     } else if (uniform_pdf) {
         dir = random_unit<R>(rng);  // uniform.rs:22-24
     } else {
@@ -1006,7 +1025,7 @@ RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathStat
         R cos_theta = dot(pdf_w, unit);                      // lambertian.rs:35-43 / glossy.rs:86-95
         scattering_pdf = cos_theta < R(0) ? R(0) : cos_theta / pi<R>();
     }
-    R second_val = lights_pdf_value<R, STATS>(sc, hit.pos, dir, cnt);
+    R second_val = lights_pdf_value<R, STATS, FULL>(sc, hit.pos, dir, cnt);
     R pdf = first_val * (R(1) - prm.light_bias) + second_val * prm.light_bias;
     // (scatter_color * attenuation * scattering_pdf) / pdf, camera.rs:312
     V3<R> w = (attenuation * scattering_pdf) / pdf;

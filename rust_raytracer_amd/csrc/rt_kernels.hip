@@ -388,7 +388,7 @@ struct DeviceScene {
             L.total_bytes = uint32_t(blob.size());
             if ((st = buf.upload(blob, &view.small_blob)) != RT_OK) return st;
         }
-        view.n_lights = int32_t(cs.lights.size());
+        view.n_lights = cs.n_top_lights;
         view.lights_is_list = cs.lights_is_list;
         view.stack_entries = int32_t(std::max(cs.max_bvh_depth + 2, cs.max_bvh4_stack + 1));
         view.n_ops = int32_t(cs.ops.size());

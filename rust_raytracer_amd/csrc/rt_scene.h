@@ -160,11 +160,13 @@ struct TextureRec {  // texture/*.rs
 constexpr int kTexStackDepth = 4;
 constexpr int32_t kTexProgShift = 20;  // program id = first op | (op count << 20)
 
-enum LightKind : int32_t { LIGHT_OTHER = 0, LIGHT_PLANE = 1, LIGHT_SPHERE = 2, LIGHT_SKY = 3, LIGHT_SUN = 4 };
+enum LightKind : int32_t { LIGHT_OTHER = 0, LIGHT_PLANE = 1, LIGHT_SPHERE = 2, LIGHT_SKY = 3, LIGHT_SUN = 4, LIGHT_LIST = 5 };
 struct LightRec {
     int32_t kind;
-    int32_t index;  // into planes / spheres / suns
+    int32_t index;  // into planes / spheres / suns; LIGHT_LIST (an ObjectList inside `lights`, e.g. an emissive box):
+                    // first member in lights[] | member count << 20 (members are stored behind the top-level entries)
 };
+constexpr int32_t kLightListShift = 20;
 
 // All the small tables (everything except BVH nodes, triangle records and attributes) are ALSO
 // uploaded as one contiguous blob, so that a workgroup can stage them in LDS with one cooperative

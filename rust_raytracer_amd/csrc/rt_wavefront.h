@@ -891,7 +891,7 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneView<R> sc_g, CameraView<
             ps.radiance = ps.radiance + ps.throughput * ld3(prm.background);
             cont = false;
         } else {
-            cont = shade_hit<R, STATS>(sc, prm, ps, hit, rng, cnt);
+            cont = shade_hit<R, STATS, TEX>(sc, prm, ps, hit, rng, cnt);
         }
         ps.depth--;
         if (cont && ps.depth != 0) {  // depth == 0: ray_color returns black without tracing (camera.rs:290)

@@ -25,6 +25,7 @@ CASES = {
     "texture_test": ["scenes/texture_test", "-w=48", "-s=16", "--seed=14"],
     "texture_mix": ["tests/scenes/texture_mix", "-w=48", "-s=16", "--seed=15"],
     "smoke": ["tests/scenes/smoke", "-w=48", "-s=16", "--seed=16"],
+    "box_light": ["tests/scenes/box_light", "-w=48", "-s=16", "--seed=17"],
 }
 
 

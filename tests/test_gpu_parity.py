@@ -43,6 +43,8 @@ SCENES = {
     "texture_mix": ["tests/scenes/texture_mix", "-w=48", "-s=16", "--seed=15"],  # every operator, every primitive's tangent frame
     # constant-density volumes (sphere / mesh / box boundaries); wavefront: combined intersect kernel, VOL variant
     "smoke": ["tests/scenes/smoke", "-w=48", "-s=16", "--seed=16"],
+    # an ObjectList (emissive box) inside `lights`: nested pdf_value / random
+    "box_light": ["tests/scenes/box_light", "-w=48", "-s=16", "--seed=17"],
 }
 
 
