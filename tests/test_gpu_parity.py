@@ -247,6 +247,24 @@ def test_full_size_frame_row_partition_and_determinism(dev):
     assert_f64_parity(full[api.owned_rows(hs.height, q)], ref)
 
 
+def test_full_frame_of_the_headline_scene_is_bit_identical_between_pipelines(dev):
+    """The whole 1200x1200 frame of the headline scene at 100 spp (4 replicas x 5x5 strata): the wavefront
+    scheduler (pool refills, in-place regeneration, replica-ordered resolve) and the per-pixel megakernel must
+    produce the same bits in every pixel."""
+    ensure_dragon()
+    hs = api.HostScene(["scenes/cornell_dragon", "-w=1200", "-s=100", "-t=4", "--seed=3"])
+    assert hs.spp == 100
+    scene = api.DeviceScene(hs.desc, 0)
+    p = hs.params.copy()
+    p.pipeline = api.RT_PIPELINE_WAVEFRONT
+    wf = scene.render(hs.camera, p)
+    p.pipeline = api.RT_PIPELINE_MEGAKERNEL
+    mega = scene.render(hs.camera, p)
+    same = (wf == mega) | (np.isnan(wf) & np.isnan(mega))
+    assert same.all(), f"{int((~same).any(axis=2).sum())} of {1200 * 1200} pixels differ"
+    assert np.isfinite(wf[..., :3]).mean() > 0.99
+
+
 def test_headline_config_rows_match_oracle(dev):
     """BASELINE.json's headline configuration itself (cornell_dragon, 1200x1200, 1000 spp = 10 replicas x 10x10
     strata, 871 200 triangles), three full rows of it (every 400th): the HIP path through the C ABI against the
