@@ -52,40 +52,103 @@ def ensure_dragon():
         os.replace(tmp, path)
 
 
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(workload: str, seed: int):
-    """Times the CPU oracle on a bounded sample of the same workload (rank 0, N=1 only)."""
+    """Times the CPU oracle on a bounded sample of the same workload (rank 0, N=1 only).
+
+    Exactly the workload's flags (same -t replicas = OS threads like the reference's -t, same s x s
+    strata, so every pixel gets the workload's spp), on an unbiased ROW subset of the frame (every
+    `stride`-th row, not a crop — BASELINE.md section 3 plans 1/16 of the rows, which is > 60 s of CPU work at
+    C4; the sample here is sized for ~20 s).  The subset is rendered as TWO disjoint interleaved halves
+    that are timed separately: their spread is the stated variance of the estimate."""
     from rust_raytracer_amd import api
     from oracle import pyoracle
 
-    cores = min(len(os.sched_getaffinity(0)), 16)
     args, _ = WORKLOADS[workload]
     hs = api.HostScene(args + [f"--seed={seed}"])
     p = hs.params.copy()
-    # Same per-sample work, bounded size: `cores` replicas of the workload's s x s strata, every
-    # `stride`-th row of the frame (an unbiased row subset, not a crop).  One OS thread per
-    # replica, exactly like the reference's -t flag.
-    p.thread_count = cores
-    target_samples = 1.2e6 * cores  # ~15-25 s at the oracle's speed on this class of host
-    per_row = hs.width * p.sqrt_spt * p.sqrt_spt * cores
-    n_rows = max(1, int(round(target_samples / per_row)))
-    stride = max(1, hs.height // n_rows)
-    p.band_rows, p.n_parts, p.part = 1, stride, stride // 2
-    t0 = time.time()
-    _, st = pyoracle.render(hs.desc, hs.camera, p)
-    wall = time.time() - t0
-    rows = len(api.owned_rows(hs.height, p))
+    avail = len(os.sched_getaffinity(0))
+    threads = p.thread_count  # one OS thread per replica (camera.rs:197-241)
+    target_samples = 1.3e6 * min(threads, avail) * 1.6  # ~20 s at the oracle's speed on this class of host
+    per_row = hs.width * p.sqrt_spt * p.sqrt_spt * threads
+    n_rows = max(2, int(round(target_samples / per_row)))
+    stride = max(2, hs.height // n_rows)
+    halves = []
+    tot_samples = tot_rays = tot_nodes = tot_tris = 0
+    tot_seconds = 0.0
+    for part in (stride // 4, stride // 4 + stride // 2):
+        q = p.copy()
+        q.band_rows, q.n_parts, q.part = 1, stride, part
+        _, st = pyoracle.render(hs.desc, hs.camera, q)
+        halves.append(st.samples / st.seconds / 1e6)
+        tot_samples += st.samples; tot_seconds += st.seconds
+        tot_rays += st.rays; tot_nodes += st.node_tests; tot_tris += st.tri_tests
+    value = tot_samples / tot_seconds / 1e6
+    rows = tot_samples // (hs.width * p.sqrt_spt * p.sqrt_spt * threads)
     return {
-        "value": st.samples / st.seconds / 1e6,
+        "value": value,
         "unit": "Msamples/s",
-        "cores": cores,
+        "cores": min(threads, avail),
         "kind": "port",
-        "sample": f"{rows} rows (every {stride}th) x {hs.width} px x {cores} replicas x {p.sqrt_spt * p.sqrt_spt} strata "
-                  f"= {st.samples} samples in {st.seconds:.1f}s (octree build {wall - st.seconds:.1f}s excluded), "
-                  f"oracle/liboracle.so -O3 x86-64-v3, f64, recursive, reference octree",
-        "rays_per_sample": st.rays / max(st.samples, 1),
-        "node_tests_per_ray": st.node_tests / max(st.rays, 1),
-        "tri_tests_per_ray": st.tri_tests / max(st.rays, 1),
+        "sample": f"{rows} of {hs.height} rows (every {stride}th, two interleaved halves) x {hs.width} px x {threads} replicas "
+                  f"(= OS threads, the workload's -t) x {p.sqrt_spt * p.sqrt_spt} strata = {tot_samples} samples in "
+                  f"{tot_seconds:.1f}s (octree build excluded); halves {halves[0]:.3f} / {halves[1]:.3f} Msamples/s "
+                  f"(spread {abs(halves[0] - halves[1]) / value:.1%}); oracle/liboracle.so -O3 x86-64-v3, f64, recursive, "
+                  f"reference octree; keyed per-sample RNG (the reference's is one sequential stream per thread)",
+        "cpu_model": cpu_model(),
+        "host_cores_available": avail,
+        "halves": halves,
+        "rays_per_sample": tot_rays / max(tot_samples, 1),
+        "node_tests_per_ray": tot_nodes / max(tot_rays, 1),
+        "tri_tests_per_ray": tot_tris / max(tot_rays, 1),
     }
+
+
+def free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) with torch.distributed.run as a
+    CHILD process.  This parent has made no GPU call (torch is not even imported yet), it only relays the
+    child's output and checks that the world that rendered is the one that was asked for."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=REPO)
+    seen = None
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        if line.startswith("{"):
+            try:
+                seen = json.loads(line)
+            except ValueError:
+                pass
+    rc = proc.wait()
+    if rc != 0:
+        return rc
+    if seen is None or seen.get("n_gpus") != n:
+        sys.stderr.write(f"bench.py: asked for {n} GPUs but the result line says {None if seen is None else seen.get('n_gpus')}\n")
+        return 3
+    return 0
 
 
 def main():
@@ -101,6 +164,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save-png", default="")
     a = ap.parse_args()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(launch_ranks(a.gpus))
 
     import torch
     import torch.distributed as dist
@@ -109,6 +176,8 @@ def main():
     from rust_raytracer_amd import dist as rtdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # Rehearsal of the multi-rank path on a one-GPU box: RT_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and uses gloo

@@ -20,7 +20,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define RT_DM_HD __host__ __device__ inline
 #else
 #define RT_DM_HD inline

@@ -219,7 +219,15 @@ typedef struct RtRenderStats {
     uint64_t bytes_node;          /* bytes per BVH node in the layout used                               */
     uint64_t bytes_tri;           /* bytes per triangle record                                           */
     uint64_t bytes_attr;          /* bytes of shading attributes fetched per mesh hit                    */
-    uint64_t bytes_state;         /* bytes of path state the dominant kernel moves per ray it handles (0: megakernel) */
+    uint64_t bytes_state;         /* bytes of path state the traversal kernel moves per ray it handles (0: megakernel) */
+    /* wavefront scheduler only (0 otherwise): HIP-event sums per kernel of the iteration loop, and the
+     * algorithmic path-state bytes (read + written) per ray that passes through each of them              */
+    double   prims_kernel_ms;     /* k_wf_prims: scene program over spheres / quads / sky / sun            */
+    double   shade_kernel_ms;     /* k_wf_shade: scatter, pdf, regeneration, queue compaction              */
+    uint64_t bytes_state_prims;
+    uint64_t bytes_state_shade;
+    uint32_t n_iterations;        /* wavefront iterations (one bounce of every live path each)             */
+    uint32_t n_replica_groups;    /* groups the replicas were rendered in (per-sample buffer budget)       */
 } RtRenderStats;
 
 typedef struct RtScene RtScene;
@@ -259,6 +267,15 @@ int rt_get_stats(const RtScene* scene, RtRenderStats* out);
 int rt_debug_trace_sample(const RtScene* scene, const RtCameraDesc* camera, const RtRenderParams* params,
                           uint32_t tid, uint32_t x, uint32_t y, uint32_t sx, uint32_t sy,
                           double* rgb_out, double* trace_out, uint32_t max_bounces);
+
+/* Diagnostic (host only, needs no device): compiles `desc` like rt_scene_create and reports how the scene
+ * compiler classified it.  RT_SCENE_INFO_ZERO_WEIGHT_STOP: the light set cannot give an infinite or NaN weight,
+ * so paths whose weight is exactly 0 are ended early (otherwise they are traced to the end like
+ * camera.rs:310-314 does); _TEX_INTERPRETER: full-feature kernel variants; _VOLUMES: combined intersect kernel. */
+#define RT_SCENE_INFO_ZERO_WEIGHT_STOP 1u
+#define RT_SCENE_INFO_TEX_INTERPRETER 2u
+#define RT_SCENE_INFO_VOLUMES 4u
+int rt_scene_info(const RtSceneDesc* desc, uint32_t* flags_out);
 
 /* Message for the last non-RT_OK status on this thread ("" if none). */
 const char* rt_last_error(void);

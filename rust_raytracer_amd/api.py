@@ -111,7 +111,10 @@ class RtRenderStats(C.Structure):
                 ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("prim_tests", C.c_uint64), ("bytes_node", C.c_uint64),
                 ("bytes_tri", C.c_uint64), ("bytes_attr", C.c_uint64),
-                ("bytes_state", C.c_uint64)]
+                ("bytes_state", C.c_uint64),
+                ("prims_kernel_ms", C.c_double), ("shade_kernel_ms", C.c_double),
+                ("bytes_state_prims", C.c_uint64), ("bytes_state_shade", C.c_uint64),
+                ("n_iterations", C.c_uint32), ("n_replica_groups", C.c_uint32)]
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -207,10 +210,25 @@ def load_device_lib() -> C.CDLL:
                                               C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                               C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_uint32]
         lib.rt_debug_trace_sample.restype = C.c_int
+        lib.rt_scene_info.argtypes = [C.POINTER(RtSceneDesc), C.POINTER(C.c_uint32)]
+        lib.rt_scene_info.restype = C.c_int
         lib.rt_last_error.argtypes = []
         lib.rt_last_error.restype = C.c_char_p
         _device_lib = lib
     return _device_lib
+
+
+RT_SCENE_INFO_ZERO_WEIGHT_STOP, RT_SCENE_INFO_TEX_INTERPRETER, RT_SCENE_INFO_VOLUMES = 1, 2, 4
+
+
+def scene_info(desc) -> int:
+    """rt_scene_info: the scene compiler's classification flags (host only, no device needed)."""
+    lib = load_device_lib()
+    flags = C.c_uint32()
+    st = lib.rt_scene_info(desc, C.byref(flags))
+    if st != RT_OK:
+        raise RtError(st, lib.rt_last_error().decode())
+    return flags.value
 
 
 def owned_rows(height: int, params: RtRenderParams) -> list:

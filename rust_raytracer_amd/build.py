@@ -5,6 +5,7 @@ repo snapshot).  hipcc cross-compiles for gfx950 without a GPU.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -19,11 +20,31 @@ DEVICE_SRC = ["rt_kernels.hip", "rt_bvh_device.hip", "rt_compile.cpp", "rt_bvh.c
 DEVICE_HDR = ["rt_device.h", "rt_wavefront.h", "rt_scene.h", "rt_compile.h", "rt_bvh.h"]
 
 
-def _newer(target: str, sources) -> bool:
+def _digest(sources, extra="") -> str:
+    h = hashlib.sha256(extra.encode())
+    for s in sources:
+        h.update(os.path.basename(s).encode())
+        with open(s, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _newer(target: str, sources, extra="") -> bool:
+    """True when `target` must be (re)built: it is missing, or the CONTENT of its sources (and the
+    flags in `extra`) differs from what it was built from (digest kept beside it in `<target>.srchash`;
+    file times are not trusted: a snapshot copied to the GPU box does not keep them)."""
     if not os.path.exists(target):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in sources)
+    try:
+        with open(target + ".srchash") as f:
+            return f.read().strip() != _digest(sources, extra)
+    except OSError:
+        return True
+
+
+def _stamp(target: str, sources, extra="") -> None:
+    with open(target + ".srchash", "w") as f:
+        f.write(_digest(sources, extra) + "\n")
 
 
 def _run(cmd, cwd=None):
@@ -48,6 +69,7 @@ def build_host(force: bool = False) -> str:
         [os.path.join(REPO_DIR, "include", h) for h in ("rt_mi355.h", "rt_host.h")]
     if force or _newer(out, deps):
         _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-o", out] + srcs + ["-lz"])
+        _stamp(out, deps)
     return out
 
 
@@ -57,10 +79,11 @@ def build_cli(force: bool = False) -> str:
     src = os.path.join(CSRC, "host", "main.cpp")
     if not os.path.exists(src):
         return ""
-    deps = [src, os.path.join(PKG_DIR, "librt_host.so"), os.path.join(PKG_DIR, "librt_mi355.so")]
+    deps = [src] + [os.path.join(REPO_DIR, "include", h) for h in ("rt_mi355.h", "rt_host.h")]
     if force or _newer(out, deps):
         _run([hipcc_path(), "-std=c++17", "-O2", "-o", out, src, "-L" + PKG_DIR, "-lrt_host", "-lrt_mi355",
               "-Wl,-rpath,$ORIGIN", "-lpthread"])
+        _stamp(out, deps)
     return out
 
 
@@ -69,13 +92,14 @@ def build_device(force: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in DEVICE_SRC]
     deps = srcs + [os.path.join(CSRC, h) for h in DEVICE_HDR] + \
         [os.path.join(REPO_DIR, "include", h) for h in ("rt_mi355.h", "rt_detmath.h")]
-    if force or _newer(out, deps):
-        extra = os.environ.get("RT_EXTRA_HIPCC_FLAGS", "").split()
+    extra = os.environ.get("RT_EXTRA_HIPCC_FLAGS", "").split()
+    if force or _newer(out, deps, " ".join(extra)):
         # -ffp-contract=off: the reference is Rust, which never fuses a*b+c; with the deterministic
         # sin/cos/log of include/rt_detmath.h the f64 kernels then follow the oracle's paths bit for
         # bit.  Measured cost on the headline scene: 3 % (the kernel is latency-bound, not FMA-bound).
         _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
               "-Wall", "-Wno-unused-function"] + extra + ["-o", out] + srcs)
+        _stamp(out, deps, " ".join(extra))
     return out
 
 
@@ -86,6 +110,7 @@ def build_oracle(force: bool = False) -> str:
             os.path.join(REPO_DIR, "include", "rt_mi355.h"), os.path.join(REPO_DIR, "include", "rt_detmath.h")]
     if force or _newer(out, deps):
         _run(["make", "-C", odir, "-B", "liboracle.so"])
+        _stamp(out, deps)
     return out
 
 
@@ -94,11 +119,13 @@ def build_tools(force: bool = False) -> str:
     src = os.path.join(REPO_DIR, "tools", "gen_dragon.cpp")
     if os.path.exists(src) and (force or _newer(out, [src])):
         _run(["g++", "-std=c++17", "-O2", "-o", out, src])
+        _stamp(out, [src])
     # micro-benchmark that pins the traversal kernel's roofline (random-line gather rates)
     ub_src = os.path.join(REPO_DIR, "tools", "ubench", "gather_lines.hip")
     ub_out = os.path.join(REPO_DIR, "tools", "ubench", "gather_lines")
     if os.path.exists(ub_src) and (force or _newer(ub_out, [ub_src])):
         _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-o", ub_out, ub_src])
+        _stamp(ub_out, [ub_src])
     return out
 
 

@@ -246,7 +246,7 @@ bool decode_jpeg(const std::vector<uint8_t>& d, std::vector<float>* rgb, uint32_
             while (i < n) {
                 int pq = s[i] >> 4, tq = s[i] & 15;
                 i++;
-                if (tq > 3) { *err = "JPEG: bad DQT"; return false; }
+                if (tq > 3 || i + (pq ? 128u : 64u) > n) { *err = "JPEG: bad DQT"; return false; }
                 for (int k = 0; k < 64; k++) {
                     if (pq) { qt[tq][kZigzag[k]] = uint16_t((s[i] << 8) | s[i + 1]); i += 2; }
                     else qt[tq][kZigzag[k]] = s[i++];
@@ -277,11 +277,13 @@ bool decode_jpeg(const std::vector<uint8_t>& d, std::vector<float>* rgb, uint32_
                 t.present = true;
             }
         } else if (m == 0xC0 || m == 0xC1) {  // SOF0 / SOF1 (Huffman, sequential)
+            if (n < 6) { *err = "JPEG: truncated SOF"; return false; }
             if (s[0] != 8) { *err = "JPEG: only 8-bit precision is supported"; return false; }
             height = (s[1] << 8) | s[2];
             width = (s[3] << 8) | s[4];
             int nc = s[5];
             if (!(nc == 1 || nc == 3)) { *err = "JPEG: only 1- or 3-component images are supported"; return false; }
+            if (n < 6 + 3 * size_t(nc)) { *err = "JPEG: truncated SOF"; return false; }
             comps.resize(size_t(nc));
             for (int c = 0; c < nc; c++) {
                 comps[c].id = s[6 + 3 * c];
@@ -295,12 +297,14 @@ bool decode_jpeg(const std::vector<uint8_t>& d, std::vector<float>* rgb, uint32_
             *err = "JPEG: progressive / arithmetic / lossless coding is not supported (baseline only)";
             return false;
         } else if (m == 0xDD) {
+            if (n < 2) { *err = "JPEG: truncated DRI"; return false; }
             restart = (s[0] << 8) | s[1];
         } else if (m == 0xEE && n >= 12 && !std::memcmp(s, "Adobe", 5)) {
             adobe = true;
             adobe_transform = s[11];
         } else if (m == 0xDA) {  // SOS: decode the (single, interleaved or not) scan
             if (!got_sof || width <= 0 || height <= 0) { *err = "JPEG: SOS before SOF"; return false; }
+            if (n < 1 || n < 1 + 2 * size_t(s[0])) { *err = "JPEG: truncated SOS"; return false; }
             int ns = s[0];
             std::vector<int> order;
             for (int k = 0; k < ns; k++) {
@@ -310,6 +314,7 @@ bool decode_jpeg(const std::vector<uint8_t>& d, std::vector<float>* rgb, uint32_
                 if (ci < 0) { *err = "JPEG: bad SOS"; return false; }
                 comps[size_t(ci)].td = s[2 + 2 * k] >> 4;
                 comps[size_t(ci)].ta = s[2 + 2 * k] & 15;
+                if (comps[size_t(ci)].td > 3 || comps[size_t(ci)].ta > 3) { *err = "JPEG: bad SOS (table selector)"; return false; }
                 order.push_back(ci);
             }
             int hmax = 1, vmax = 1;

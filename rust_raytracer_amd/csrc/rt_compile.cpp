@@ -541,6 +541,115 @@ struct Compiler {
         uint32_t root = d.lights_root;
         return compile_light_entries(&root, 1);
     }
+
+    // ---- CompiledScene::zero_weight_stop ----
+    // A pdf-sampled vertex (Lambertian / Glossy diffuse lobe / Isotropic) gets an infinite or NaN weight only if
+    // mix_pdf.value == 0 or the sampled direction is NaN.  The material's own pdf is > 0 for its own samples, so
+    // this needs a LIGHT sample (mix.rs:23-36) whose direction no light's pdf_value covers, or a NaN from
+    // Sphere::random (origin inside the sphere: sqrt of a negative number, sphere.rs:123-145).  Ruled out when
+    //   * `lights` (and every list inside it) is non-empty                                       (list.rs:93-95),
+    //   * every light is a two-sided quad (a one-sided quad's pdf_value is 0 from behind, plane.rs:74,107-118),
+    //     a sphere, the sky or the sun (Transform / mesh / bvh / volume lights have pdf_value 0),
+    //   * quads and spheres used as lights do not scatter with a pdf themselves (a point ON the light samples
+    //     the light from its own surface: in-plane directions, |c - p| < r by rounding),
+    //   * no pdf-scattering object of the world reaches inside a sphere light (conservative box test).
+    // What remains are rounding-level events (a sampled point on the very edge of a quad or of a sphere's cone
+    // failing the re-intersection): probability of the order of 2^-50 per light sample.
+    bool scatters_with_pdf(int32_t material) const {
+        if (material < 0 || uint32_t(material) >= d.n_materials) return true;
+        const uint32_t t = d.materials[material].type;
+        return t == RT_MAT_LAMBERTIAN || t == RT_MAT_GLOSSY || t == RT_MAT_ISOTROPIC;
+    }
+    bool subtree_scatters_with_pdf(uint32_t node, int depth) const {
+        if (node >= d.n_nodes || depth > 512) return true;
+        const RtNode& n = d.nodes[node];
+        switch (n.type) {
+            case RT_NODE_SPHERE: case RT_NODE_PLANE: case RT_NODE_MESH: case RT_NODE_SKY: case RT_NODE_SUN:
+                return scatters_with_pdf(n.material);
+            case RT_NODE_VOLUME:
+                return true;  // Isotropic medium
+            case RT_NODE_NULL:
+                return false;
+            default:
+                for (uint32_t k = 0; k < n.n_children; k++)
+                    if (subtree_scatters_with_pdf(d.child_indices[n.first_child + k], depth + 1)) return true;
+                return false;
+        }
+    }
+    // Can a pdf-scattering surface of the subtree `node` lie inside the ball (centre c, radius r, world space)?
+    // `m` = object-to-world matrix of the space `node` lives in (row-major 3x4).  Boxes are the reference's
+    // get_bounding_box() values, moved to world space corner by corner (a Transform node's own box is NOT used:
+    // Transform::update_bounds has a quirk, transform.rs:98-118, SURVEY B-7; its child is entered instead).
+    bool pdf_surface_inside_ball(uint32_t node, const double c[3], double r, const double m[12], int depth) const {
+        if (node >= d.n_nodes || depth > 512) return true;
+        const RtNode& n = d.nodes[node];
+        if (n.type == RT_NODE_TRANSFORM) {
+            if (n.n_children != 1 || n.transform < 0 || uint32_t(n.transform) >= d.n_transforms) return true;
+            const double* t = d.transforms[n.transform].m;  // row-major 4x4, last row 0 0 0 1
+            double mt[12];
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 4; j++)
+                    mt[4 * i + j] = m[4 * i] * t[j] + m[4 * i + 1] * t[4 + j] + m[4 * i + 2] * t[8 + j] + (j == 3 ? m[4 * i + 3] : 0.0);
+            return pdf_surface_inside_ball(d.child_indices[n.first_child], c, r, mt, depth + 1);
+        }
+        if (n.type == RT_NODE_NULL) return false;
+        if (n.type == RT_NODE_SKY || n.type == RT_NODE_SUN) return false;  // at infinity (their own materials are Emissive)
+        double lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+        for (int corner = 0; corner < 8; corner++) {
+            const double p[3] = {n.bounds[(corner & 1) ? 3 : 0], n.bounds[(corner & 2) ? 4 : 1], n.bounds[(corner & 4) ? 5 : 2]};
+            for (int a = 0; a < 3; a++) {
+                const double w = m[4 * a] * p[0] + m[4 * a + 1] * p[1] + m[4 * a + 2] * p[2] + m[4 * a + 3];
+                lo[a] = std::fmin(lo[a], w);
+                hi[a] = std::fmax(hi[a], w);
+            }
+        }
+        double d2 = 0.0;  // squared distance from the centre to the box
+        for (int a = 0; a < 3; a++) {
+            const double x = c[a] < lo[a] ? lo[a] - c[a] : (c[a] > hi[a] ? c[a] - hi[a] : 0.0);
+            d2 += x * x;
+        }
+        if (d2 > r * r) return false;  // the box is outside the ball (NaN: undecided -> go on)
+        if (n.type == RT_NODE_LIST || n.type == RT_NODE_BVH) {
+            for (uint32_t k = 0; k < n.n_children; k++)
+                if (pdf_surface_inside_ball(d.child_indices[n.first_child + k], c, r, m, depth + 1)) return true;
+            return false;
+        }
+        return subtree_scatters_with_pdf(node, depth);
+    }
+    bool light_is_safe(uint32_t node, bool nested) const {
+        const RtNode& n = d.nodes[node];
+        switch (n.type) {
+            case RT_NODE_PLANE:
+                return (n.flags & RT_PLANE_RENDER_BACKFACE) != 0 && !scatters_with_pdf(n.material);
+            case RT_NODE_SPHERE: {
+                if (scatters_with_pdf(n.material)) return false;
+                const double r = std::fabs(n.p[3]) * (1.0 + 1e-9);
+                const double identity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+                return !pdf_surface_inside_ball(d.world_root, n.p, r, identity, 0);
+            }
+            case RT_NODE_SKY: case RT_NODE_SUN:
+                return true;
+            case RT_NODE_LIST: {
+                if (nested || n.n_children == 0) return false;
+                for (uint32_t k = 0; k < n.n_children; k++)
+                    if (!light_is_safe(d.child_indices[n.first_child + k], true)) return false;
+                return true;
+            }
+            default:
+                return false;
+        }
+    }
+    void decide_zero_weight_stop() {
+        const RtNode& n = d.nodes[d.lights_root];
+        bool ok;
+        if (n.type == RT_NODE_LIST) {
+            ok = n.n_children > 0;
+            for (uint32_t k = 0; ok && k < n.n_children; k++) ok = light_is_safe(d.child_indices[n.first_child + k], false);
+        } else {
+            ok = light_is_safe(d.lights_root, false);
+        }
+        out.zero_weight_stop = ok;
+    }
 };
 
 }  // namespace
@@ -563,6 +672,7 @@ int compile_scene(const RtSceneDesc* desc, CompiledScene* out, std::string* err,
     c.chain.clear();
     out->ops.push_back({OP_END, 0, 0, c.chain_id()});
     if (!c.compile_lights()) return c.status;
+    c.decide_zero_weight_stop();
     out->chain_offsets.push_back(0);
     for (auto& ch : c.chains) {
         out->chain_items.insert(out->chain_items.end(), ch.begin(), ch.end());

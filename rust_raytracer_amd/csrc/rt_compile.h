@@ -37,6 +37,12 @@ struct CompiledScene {
     int32_t lights_is_list = 0;
     int32_t n_top_lights = 0;                  // entries of `lights` itself (members of nested lists follow in `lights`)
     uint32_t max_bvh_depth = 1;
+    // A path whose running weight is exactly zero contributes 0 unless a LATER vertex produces an infinite or NaN
+    // weight (0 * inf = NaN in the reference's `(L * att * s_pdf) / pdf`, camera.rs:312).  Such weights need pdf == 0
+    // (or a NaN direction) at a pdf-sampled vertex, i.e. a light sample that no light's pdf_value covers.  True when
+    // the light set rules that out (see Compiler::decide_zero_weight_stop); the kernels then end zero-weight paths,
+    // otherwise they trace them to the end like the reference.
+    bool zero_weight_stop = false;
 };
 
 struct CompileOptions {

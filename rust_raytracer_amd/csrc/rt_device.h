@@ -908,14 +908,39 @@ RT_DEV Ray<R> get_ray(const CameraView<R>& cam, uint32_t px, uint32_t py, uint32
 }
 
 // ------------------------------------------------------------------ one path vertex (camera.rs:282-332)
-// State of a path in the iterative form L = sum_k T_k E_k + T_end BG.
+// The reference's recursion returns, for one camera sample, a single PRODUCT: every vertex either ends the path with a
+// terminal value T (emission camera.rs:327, background :331, black for Absorbed :326 and for depth == 0 :290) or
+// multiplies what its continuation returns by a weight (att * s_pdf / pdf, :312, or att, :320); `from_emission` of a
+// scattering material is the zero vector (material.rs:42-44).  The iterative form carries the running product
+// `throughput` W forward and sets  L = W * T  at the terminal.  IEEE special values come out like the reference's
+// nested evaluation: a factor that is NaN, or a zero factor together with an infinite one, gives NaN in either order
+// (e.g. the 0/0 weight of a light sample that misses every light and points below the surface).
 template <typename R>
 struct PathState {
     Ray<R> ray;
     V3<R> throughput;
-    V3<R> radiance;
+    V3<R> radiance;  // written once, at the terminal
     uint32_t depth;  // remaining depth, like the `depth` argument of ray_color
 };
+
+// Early ends that cannot change the sample's value.  (1) W is NaN in every channel: so is W * T whatever follows.
+// (2) W is zero in every channel and the scene is one whose vertices cannot produce an infinite or NaN weight
+// (SceneView::stop_on_zero_weight, decided by the scene compiler): the continuation returns something finite and
+// L = 0.  Every other path is traced to its end like the reference does.
+template <typename R> RT_DEV bool path_goes_on(const SceneView<R>& sc, PathState<R>& ps) {
+    const V3<R> w = ps.throughput;
+    if (w.x != w.x && w.y != w.y && w.z != w.z) {
+        ps.radiance = w;
+        return false;
+    }
+    if (sc.stop_on_zero_weight && w.x == R(0) && w.y == R(0) && w.z == R(0)) {
+        ps.radiance = w;
+        return false;
+    }
+    return true;
+}
+// Black terminal (Absorbed, depth exhausted): W * 0 is 0 unless W holds an infinity or a NaN.
+template <typename R> RT_DEV void end_black(PathState<R>& ps) { ps.radiance = ps.throughput * R(0); }
 
 // Shades the closest hit; returns true if the path continues with ps.ray updated.
 template <typename R, bool STATS, bool FULL>
@@ -924,7 +949,7 @@ RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathStat
 template <typename R, bool STATS, bool TEX = false>
 RT_DEV bool shade(const SceneView<R>& sc, const ParamsView<R>& prm, PathState<R>& ps, const Best<R>& best, Rng& rng, LaneCounters& cnt) {
     if (best.pc < 0) {  // camera.rs:331 background
-        ps.radiance = ps.radiance + ps.throughput * ld3(prm.background);
+        ps.radiance = ps.throughput * ld3(prm.background);
         return false;
     }
     const HitInfo<R> hit = resolve_hit<R, TEX>(sc, ps.ray, best);
@@ -943,11 +968,12 @@ RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathStat
     bool uniform_pdf = false;
     switch (mat.type) {
         case RT_MAT_EMISSIVE: {  // emissive.rs:24-34; camera.rs:327
-            if (hit.front_face) ps.radiance = ps.radiance + ps.throughput * hit.tex_a;
+            if (hit.front_face) ps.radiance = ps.throughput * hit.tex_a;
+            else end_black(ps);  // emissive.rs:31-33
             return false;
         }
         case RT_MAT_NORMAL_DEBUG: {  // normal_debug.rs:42-48
-            ps.radiance = ps.radiance + ps.throughput * (hit.normal * R(0.5) + mk<R>(R(0.5), R(0.5), R(0.5)));
+            ps.radiance = ps.throughput * (hit.normal * R(0.5) + mk<R>(R(0.5), R(0.5), R(0.5)));
             return false;
         }
         case RT_MAT_LAMBERTIAN:  // lambertian.rs:25-33
@@ -963,10 +989,10 @@ RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathStat
         case RT_MAT_METAL: {  // metal.rs:28-44
             V3<R> reflected = reflect(ps.ray.d, hit.normal);
             V3<R> scatter_dir = reflected + random_unit<R>(rng) * hit.tex_b * length(reflected);
-            if (!(dot(scatter_dir, hit.normal) > R(0))) return false;  // Absorbed (camera.rs:326)
+            if (!(dot(scatter_dir, hit.normal) > R(0))) { end_black(ps); return false; }  // Absorbed (camera.rs:326)
             ps.throughput = ps.throughput * hit.tex_a;
             ps.ray = make_ray(hit.pos, scatter_dir);
-            return true;
+            return path_goes_on(sc, ps);
         }
         case RT_MAT_DIELECTRIC: {  // dielectric.rs:29-54
             R ior = sc.material_params[hit.material].ior;
@@ -989,7 +1015,7 @@ RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathStat
                 R roughness = hit.tex_b;
                 V3<R> reflected = reflect(ps.ray.d, normal);
                 V3<R> scatter_dir = reflected + random_unit<R>(rng) * roughness * length(reflected);
-                if (!(dot(scatter_dir, normal) > R(0))) return false;  // Absorbed
+                if (!(dot(scatter_dir, normal) > R(0))) { end_black(ps); return false; }  // Absorbed
                 ps.ray = make_ray(hit.pos, scatter_dir);               // attenuation (1,1,1)
                 return true;
             }
@@ -999,9 +1025,10 @@ RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathStat
             break;
         }
         default:
+            end_black(ps);
             return false;
     }
-    if (!with_pdf) return false;
+    if (!with_pdf) { end_black(ps); return false; }
 
     // ScatteredWithPDF: camera.rs:298-315 with MixPDF (mix.rs:23-36)
     V3<R> dir;
@@ -1031,15 +1058,7 @@ RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathStat
     V3<R> w = (attenuation * scattering_pdf) / pdf;
     ps.throughput = ps.throughput * w;
     ps.ray = make_ray(hit.pos, dir);
-    // A weight of exactly zero multiplies everything the continuation could return: stop here.
-    if (w.x == R(0) && w.y == R(0) && w.z == R(0)) return false;
-    // 0/0 (scattering_pdf == 0 and pdf == 0, e.g. a light sample that misses every light and
-    // points below the surface): the reference's `(L * att * 0) / 0` is NaN whatever L is.
-    if (w.x != w.x || w.y != w.y || w.z != w.z) {
-        ps.radiance = ps.radiance + w;
-        return false;
-    }
-    return true;
+    return path_goes_on(sc, ps);
 }
 
 }  // namespace rt

@@ -77,11 +77,15 @@ __global__ void __launch_bounds__(256) k_megakernel(SceneView<R> sc, CameraView<
             sample++;
         }
         bool cont = false;
-        if (ps.depth != 0) {  // camera.rs:290
+        if (ps.depth != 0) {
             Best<R> best;
             world_test<R, STATS, TEX>(sc, ps.ray, R(0.001), best, stack, stride, cnt, &rng);  // TEX variant = full feature set (+ volumes)
             cont = shade<R, STATS, TEX>(sc, prm, ps, best, rng, cnt);
             ps.depth--;
+            if (cont && ps.depth == 0) {  // ray_color(depth == 0) returns black without tracing (camera.rs:290)
+                end_black(ps);
+                cont = false;
+            }
         }
         if (!cont) {
             alive = false;
@@ -149,6 +153,7 @@ __global__ void k_trace_sample(SceneView<R> sc, CameraView<R> cam, ParamsView<R>
         n++;
         bool cont = shade<R, false, true>(sc, prm, ps, best, rng, cnt);  // the general (interpreter) texture path
         ps.depth--;
+        if (cont && ps.depth == 0) end_black(ps);
         if (!cont) break;
     }
     rgb[0] = double(ps.radiance.x); rgb[1] = double(ps.radiance.y); rgb[2] = double(ps.radiance.z);
@@ -390,6 +395,8 @@ struct DeviceScene {
         }
         view.n_lights = cs.n_top_lights;
         view.lights_is_list = cs.lights_is_list;
+        view.stop_on_zero_weight = cs.zero_weight_stop ? 1 : 0;
+        if (const char* e = std::getenv("RT_ZERO_WEIGHT_STOP")) view.stop_on_zero_weight = std::atoi(e) != 0;  // experiments
         view.stack_entries = int32_t(std::max(cs.max_bvh_depth + 2, cs.max_bvh4_stack + 1));
         view.n_ops = int32_t(cs.ops.size());
         // The uploads above went through the null stream (small pageable copies may return once
@@ -520,14 +527,28 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
     return uint32_t(std::strtoul(v, nullptr, 10));
 }
 
-template <typename R>
-int wf_ensure(RtScene* s, uint32_t capacity) {
-    RtScene::Wavefront& w = s->wf;
-    if (w.capacity == capacity && w.real_size == sizeof(R)) return RT_OK;
+// Releases the path pool and its queues and marks the pool as absent, so that a failed re-allocation can never be
+// mistaken for a valid pool by a later render (and nothing is freed twice by rt_scene_destroy).
+static void wf_release_pool(RtScene::Wavefront& w) {
+    w.capacity = 0;
+    w.real_size = 0;
     for (void* p : w.allocs) (void)hipFree(p);
     w.allocs.clear();
     ::operator delete(w.pool_view);
     w.pool_view = nullptr;
+    for (int q = 0; q < 2; q++) {
+        if (w.queue[q]) (void)hipFree(w.queue[q]);
+        w.queue[q] = nullptr;
+    }
+    if (w.mesh_queue) (void)hipFree(w.mesh_queue);
+    w.mesh_queue = nullptr;
+}
+
+template <typename R>
+int wf_ensure(RtScene* s, uint32_t capacity) {
+    RtScene::Wavefront& w = s->wf;
+    if (w.capacity == capacity && w.real_size == sizeof(R)) return RT_OK;
+    wf_release_pool(w);
     auto* pool = new WfPool<R>();
     w.pool_view = pool;
     pool->capacity = capacity;
@@ -536,26 +557,30 @@ int wf_ensure(RtScene* s, uint32_t capacity) {
         w.allocs.push_back(*out);
         return RT_OK;
     };
-    R** reals[] = {&pool->ox, &pool->oy, &pool->oz, &pool->dx, &pool->dy, &pool->dz, &pool->tr, &pool->tg, &pool->tb,
-                   &pool->lr, &pool->lg, &pool->lb, &pool->ht, &pool->hu, &pool->hv};
-    for (R** r : reals)
-        if (int st = alloc(size_t(capacity) * sizeof(R), reinterpret_cast<void**>(r))) return st;
-    if (int st = alloc(size_t(capacity) * 8, reinterpret_cast<void**>(&pool->rng))) return st;
-    if (int st = alloc(size_t(capacity) * 8, reinterpret_cast<void**>(&pool->sample))) return st;
-    if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->depth))) return st;
-    if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->hpc))) return st;
-    if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->htri))) return st;
-    for (int q = 0; q < 2; q++) {
-        if (w.queue[q]) (void)hipFree(w.queue[q]);
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.queue[q]), size_t(capacity) * 4));
-    }
-    if (w.mesh_queue) (void)hipFree(w.mesh_queue);
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.mesh_queue), size_t(capacity) * 4));
-    if (!w.d_ctr) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.d_ctr), sizeof(WfCounters)));
-    if (!w.h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w.h_ctr), sizeof(WfCounters)));
-    if (w.events.empty()) {
-        w.events.resize(64);
-        for (auto& e : w.events) HIP_TRY(hipEventCreate(&e));
+    auto build = [&]() -> int {
+        R** reals[] = {&pool->ox, &pool->oy, &pool->oz, &pool->dx, &pool->dy, &pool->dz, &pool->tr, &pool->tg, &pool->tb,
+                       &pool->ht, &pool->hu, &pool->hv};
+        for (R** r : reals)
+            if (int st = alloc(size_t(capacity) * sizeof(R), reinterpret_cast<void**>(r))) return st;
+        if (int st = alloc(size_t(capacity) * 8, reinterpret_cast<void**>(&pool->rng))) return st;
+        if (int st = alloc(size_t(capacity) * 8, reinterpret_cast<void**>(&pool->sample))) return st;
+        if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->depth))) return st;
+        if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->hpc))) return st;
+        if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->htri))) return st;
+        for (int q = 0; q < 2; q++) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.queue[q]), size_t(capacity) * 4));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.mesh_queue), size_t(capacity) * 4));
+        if (!w.d_ctr) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.d_ctr), sizeof(WfCounters)));
+        if (!w.h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w.h_ctr), sizeof(WfCounters)));
+        if (w.events.empty()) {
+            w.events.resize(128);  // 4 per iteration, up to 32 iterations between host checks
+            for (auto& e : w.events) e = nullptr;
+            for (auto& e : w.events) HIP_TRY(hipEventCreate(&e));
+        }
+        return RT_OK;
+    };
+    if (int st = build()) {
+        wf_release_pool(w);  // e.g. out of memory half way: leave no half-built pool behind
+        return st;
     }
     w.capacity = capacity;
     w.real_size = sizeof(R);
@@ -649,15 +674,18 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     // small tables staged in LDS by the prims / shade kernels when they fit
     const bool lds_tables = ds.view.lay.total_bytes <= 48u * 1024u && env_u32("RT_LDS_TABLES", 1) != 0;
     const size_t lds_small = lds_tables ? size_t(ds.view.lay.total_bytes) : 0;
-    const uint32_t check_every = std::min<uint32_t>(32u, std::max<uint32_t>(1u, env_u32("RT_WF_CHECK", 8)));  // 2 timing events per iteration, 64 events
+    const uint32_t check_every = std::min<uint32_t>(32u, std::max<uint32_t>(1u, env_u32("RT_WF_CHECK", 8)));  // 4 timing events per iteration, 128 events
     const bool tex = s->compiled.needs_tex_interpreter;
     const size_t shade_lds_pad = env_u32("RT_WF_SHADE_LDS_PAD", 0);  // experiments: fewer resident blocks of the shade kernel
 
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    double isect_ms = 0.0;
-    uint32_t isect_launches = 0;
+    // HIP-event sums per kernel of the iteration loop: 4 events per iteration (before prims / intersect, after it,
+    // after the mesh kernel, after shade); slot 0 = prims, 1 = traversal (mesh or combined intersect), 2 = shade
+    double phase_ms[3] = {0.0, 0.0, 0.0};
+    uint32_t isect_launches = 0, n_groups = 0;
     for (uint32_t t0 = 0; t0 < T; t0 += group) {
+        n_groups++;
         uint32_t nrep = std::min(group, T - t0);
         WfGroup<R> grp{};
         grp.total = per_replica * nrep;
@@ -680,6 +708,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
         for (;;) {
             size_t ev = 0;
             for (uint32_t k = 0; k < check_every; k++) {
+                HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 if (split || prims_only) {
 #define RT_LAUNCH_PRIMS(ST, L) hipLaunchKernelGGL((k_wf_prims<R, ST, L>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), lds_small + (WF_CHUNK + 4) * 4, stream, ds.view, pool, w.queue[qi], w.mesh_queue, w.d_ctr, s->d_counters, mesh_pc)
                     if (stats) { if (lds_tables) RT_LAUNCH_PRIMS(true, true); else RT_LAUNCH_PRIMS(true, false); }
@@ -707,17 +736,19 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
                 else { if (lds_tables) RT_LAUNCH_SHADE(false, true, false); else RT_LAUNCH_SHADE(false, false, false); }
 #undef RT_LAUNCH_SHADE
                 hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(1), 0, stream, w.d_ctr);
+                HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 qi ^= 1;
                 isect_launches++;
             }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(w.h_ctr, w.d_ctr, sizeof(WfCounters), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
-            for (size_t e = 0; e + 1 < ev; e += 2) {
-                float ms = 0.f;
-                HIP_TRY(hipEventElapsedTime(&ms, w.events[e], w.events[e + 1]));
-                isect_ms += ms;
-            }
+            for (size_t e = 0; e + 3 < ev; e += 4)
+                for (int ph = 0; ph < 3; ph++) {
+                    float ms = 0.f;
+                    HIP_TRY(hipEventElapsedTime(&ms, w.events[e + ph], w.events[e + ph + 1]));
+                    phase_ms[ph] += ms;
+                }
             upper = w.h_ctr->n_in;
             if (upper == 0) break;
         }
@@ -734,8 +765,12 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     RtRenderStats& st = s->stats;
     st = RtRenderStats{};
     st.kernel_ms = ms;
-    st.traversal_kernel_ms = isect_ms;
+    st.traversal_kernel_ms = prims_only ? 0.0 : phase_ms[1];
+    st.prims_kernel_ms = (split || prims_only) ? phase_ms[0] : 0.0;
+    st.shade_kernel_ms = phase_ms[2];
     st.n_launches = isect_launches;
+    st.n_iterations = isect_launches;
+    st.n_replica_groups = n_groups;
     if (stats && split && env_u32("RT_WF_DEBUG", 0)) {
         auto pct = [](unsigned long long lanes, unsigned long long waves) { return waves ? 100.0 * double(lanes) / (64.0 * double(waves)) : 0.0; };
         std::fprintf(stderr,
@@ -757,6 +792,10 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     // path state moved by the DOMINANT kernel per ray it traverses: ray (6 R) + bound/op read (R + 4)
     // + hit written when a triangle wins (3 R + 8) + queue entry (4)
     st.bytes_state = 6 * sizeof(R) + sizeof(R) + 4 + 3 * sizeof(R) + 8 + 4;
+    // k_wf_prims per ray: ray in (6 R), closest hit out (3 R + 8); k_wf_shade per ray: ray + hit + throughput + rng + depth +
+    // sample index in, ray + throughput + rng + depth out (a path that ends writes 24 B of radiance instead and restarts)
+    st.bytes_state_prims = 6 * sizeof(R) + 3 * sizeof(R) + 8;
+    st.bytes_state_shade = (6 + 3 + 3) * sizeof(R) + 8 + 8 + 4 + 8 + (6 + 3) * sizeof(R) + 8 + 4;
     if (!split) st.mesh_rays = hc.rays;  // combined kernel: every ray's state passes through it
     return RT_OK;
 }
@@ -828,17 +867,14 @@ void rt_scene_destroy(RtScene* s) {
     (void)hipSetDevice(s->device);
     s->f64.reset();
     s->f32.reset();
-    for (void* p : s->wf.allocs) (void)hipFree(p);
-    if (s->wf.queue[0]) (void)hipFree(s->wf.queue[0]);
-    if (s->wf.queue[1]) (void)hipFree(s->wf.queue[1]);
-    if (s->wf.mesh_queue) (void)hipFree(s->wf.mesh_queue);
+    rt::wf_release_pool(s->wf);
     if (s->wf.mesh_spill) (void)hipFree(s->wf.mesh_spill);
     if (s->wf.d_ctr) (void)hipFree(s->wf.d_ctr);
     if (s->wf.h_ctr) (void)hipHostFree(s->wf.h_ctr);
     if (s->wf.sample_L) (void)hipFree(s->wf.sample_L);
     if (s->wf.acc) (void)hipFree(s->wf.acc);
-    for (hipEvent_t e : s->wf.events) (void)hipEventDestroy(e);
-    ::operator delete(s->wf.pool_view);
+    for (hipEvent_t e : s->wf.events)
+        if (e) (void)hipEventDestroy(e);
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -941,6 +977,18 @@ int rt_debug_trace_sample(const RtScene* scene, const RtCameraDesc* camera, cons
     uint32_t n;
     std::memcpy(&n, h.data() + 3 + size_t(max_bounces) * 17, sizeof n);
     return int(n);
+}
+
+int rt_scene_info(const RtSceneDesc* desc, uint32_t* flags_out) {
+    using namespace rt;
+    if (!desc || !flags_out) return set_err(RT_E_INVALID, "rt_scene_info: NULL argument");
+    CompiledScene cs;
+    std::string err;
+    int st = compile_scene(desc, &cs, &err, CompileOptions());
+    if (st != RT_OK) return set_err(st, err);
+    *flags_out = (cs.zero_weight_stop ? RT_SCENE_INFO_ZERO_WEIGHT_STOP : 0u) | (cs.needs_tex_interpreter ? RT_SCENE_INFO_TEX_INTERPRETER : 0u) |
+                 (cs.volumes.empty() ? 0u : RT_SCENE_INFO_VOLUMES);
+    return RT_OK;
 }
 
 int rt_get_stats(const RtScene* scene, RtRenderStats* out) {

@@ -204,6 +204,7 @@ struct SceneView {
     const LightRec* lights;
     int32_t n_lights;
     int32_t lights_is_list;  // lights root is an ObjectList (list.rs:80-100) vs a single object
+    int32_t stop_on_zero_weight;  // CompiledScene::zero_weight_stop: a path whose throughput is exactly 0 may end (rt_device.h, path_goes_on)
     int32_t stack_entries;   // per-lane LDS traversal stack size
     int32_t n_ops;
     const char* small_blob;  // the tables above packed per SmallLayout (global memory)

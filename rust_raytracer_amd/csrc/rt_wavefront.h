@@ -41,8 +41,7 @@ template <typename R>
 struct WfPool {
     uint32_t capacity;
     R *ox, *oy, *oz, *dx, *dy, *dz;  // current ray, world space
-    R *tr, *tg, *tb;                 // throughput T_k
-    R *lr, *lg, *lb;                 // radiance accumulated so far
+    R *tr, *tg, *tb;                 // throughput: product of the weights so far (the radiance exists only at the terminal)
     uint64_t* rng;                   // stream state
     uint64_t* sample;                // sample index within the current replica group
     uint32_t* depth;                 // remaining depth (the `depth` argument of ray_color)
@@ -88,7 +87,6 @@ RT_DEV void wf_start_sample(const WfPool<R>& pool, uint32_t slot, uint64_t s, co
     pool.ox[slot] = ray.o.x; pool.oy[slot] = ray.o.y; pool.oz[slot] = ray.o.z;
     pool.dx[slot] = ray.d.x; pool.dy[slot] = ray.d.y; pool.dz[slot] = ray.d.z;
     pool.tr[slot] = R(1); pool.tg[slot] = R(1); pool.tb[slot] = R(1);
-    pool.lr[slot] = R(0); pool.lg[slot] = R(0); pool.lb[slot] = R(0);
     pool.rng[slot] = rng.s;
     pool.sample[slot] = s;
     pool.depth[slot] = cam.max_depth;
@@ -882,13 +880,13 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneView<R> sc_g, CameraView<
         if (best.pc >= 0) hit = resolve_hit<R, TEX>(sc, ps.ray, best);
         asm volatile("" ::: "memory");
         ps.throughput = mk<R>(pool.tr[slot], pool.tg[slot], pool.tb[slot]);
-        ps.radiance = mk<R>(pool.lr[slot], pool.lg[slot], pool.lb[slot]);
+        ps.radiance = mk<R>(0, 0, 0);
         ps.depth = pool.depth[slot];
         Rng rng;
         rng.s = pool.rng[slot];
         bool cont;
         if (best.pc < 0) {  // camera.rs:331 background
-            ps.radiance = ps.radiance + ps.throughput * ld3(prm.background);
+            ps.radiance = ps.throughput * ld3(prm.background);
             cont = false;
         } else {
             cont = shade_hit<R, STATS, TEX>(sc, prm, ps, hit, rng, cnt);
@@ -898,11 +896,11 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneView<R> sc_g, CameraView<
             pool.ox[slot] = ps.ray.o.x; pool.oy[slot] = ps.ray.o.y; pool.oz[slot] = ps.ray.o.z;
             pool.dx[slot] = ps.ray.d.x; pool.dy[slot] = ps.ray.d.y; pool.dz[slot] = ps.ray.d.z;
             pool.tr[slot] = ps.throughput.x; pool.tg[slot] = ps.throughput.y; pool.tb[slot] = ps.throughput.z;
-            pool.lr[slot] = ps.radiance.x; pool.lg[slot] = ps.radiance.y; pool.lb[slot] = ps.radiance.z;
             pool.rng[slot] = rng.s;
             pool.depth[slot] = ps.depth;
             alive = true;
         } else {
+            if (cont) end_black(ps);  // depth exhausted: the next ray_color call returns black (camera.rs:290)
             uint64_t s = pool.sample[slot];
             sample_L[3 * s + 0] = double(ps.radiance.x);
             sample_L[3 * s + 1] = double(ps.radiance.y);

@@ -14,13 +14,14 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session", autouse=True)
 def _built():
-    """Native libraries are built in-tree; on the GPU box the prebuilt .so files are used as-is
-    (the build step is a no-op when they are newer than their sources)."""
+    """Native libraries are built in-tree.  Every library is rebuilt when the CONTENT of its sources differs
+    from what it was built from (digest beside the .so, rust_raytracer_amd/build.py), so a stale prebuilt
+    library can never be what the tests run — here or on the GPU box (hipcc is in the image there too)."""
     from rust_raytracer_amd import build as b
     b.build_host()
+    b.build_device()
+    b.build_cli()
     b.build_oracle()
-    if not os.path.exists(os.path.join(REPO, "rust_raytracer_amd", "librt_mi355.so")):
-        b.build_device()
     b.build_tools()
     yield
 

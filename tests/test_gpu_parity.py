@@ -45,6 +45,10 @@ SCENES = {
     "smoke": ["tests/scenes/smoke", "-w=48", "-s=16", "--seed=16"],
     # an ObjectList (emissive box) inside `lights`: nested pdf_value / random
     "box_light": ["tests/scenes/box_light", "-w=48", "-s=16", "--seed=17"],
+    # zero-weight vertices (black albedo, light samples below the horizon) in front of 0/0 vertices (one-sided light seen
+    # from behind): the reference's 0 * NaN; 259 of these 2304 pixels are NaN ONLY through a zero-weight prefix
+    # (tests/test_zero_weight.py), so a kernel that ends zero-weight paths early fails here
+    "zero_weight_nan": ["tests/scenes/zero_weight_nan", "-w=48", "-s=16", "--seed=18"],
 }
 
 
@@ -99,6 +103,72 @@ def test_pipelines_are_bit_identical_and_small_pool_works(dev, monkeypatch):
     np.testing.assert_array_equal(scene.render(hs.camera, p), mega)
     monkeypatch.setenv("RT_WF_REFILL", "64")
     np.testing.assert_array_equal(scene.render(hs.camera, p), mega)
+
+
+def test_zero_weight_paths_are_traced_unless_the_light_set_is_safe(dev, monkeypatch):
+    """camera.rs:310-314: `(L * att * s_pdf) / pdf` with a zero weight is NaN when L is.  (1) In a scene with a
+    one-sided light the NaN mask must be the oracle's (also covered per pipeline by test_f64_matches_oracle) and the
+    GPU must trace exactly as many rays as the reference does.  (2) In scenes the compiler classifies as safe the
+    early end must not change a single bit: same frame with the early end switched off."""
+    hs = api.HostScene(SCENES["zero_weight_nan"])
+    assert not api.scene_info(hs.desc) & api.RT_SCENE_INFO_ZERO_WEIGHT_STOP
+    ref, ost = pyoracle.render(hs.desc, hs.camera, hs.params)
+    p = hs.params.copy()
+    p.collect_stats = 1
+    scene = api.DeviceScene(hs.desc, 0)
+    gpu = scene.render(hs.camera, p)
+    nan_ref = np.isnan(ref[..., :3]).any(axis=2)
+    assert 0.3 < nan_ref.mean() < 0.8
+    np.testing.assert_array_equal(np.isnan(gpu[..., :3]), np.isnan(ref[..., :3]))
+    assert_f64_parity(gpu, ref)
+    assert scene.stats().rays == ost.rays          # nothing is cut short
+    for name in ("cornell", "light_test", "default"):
+        hs = api.HostScene(SCENES[name])
+        assert api.scene_info(hs.desc) & api.RT_SCENE_INFO_ZERO_WEIGHT_STOP
+        monkeypatch.delenv("RT_ZERO_WEIGHT_STOP", raising=False)
+        q = hs.params.copy()
+        q.collect_stats = 1
+        s1 = api.DeviceScene(hs.desc, 0)
+        fast = s1.render(hs.camera, q)
+        rays_fast = s1.stats().rays
+        monkeypatch.setenv("RT_ZERO_WEIGHT_STOP", "0")   # read when the device tables are built
+        s2 = api.DeviceScene(hs.desc, 0)
+        exact = s2.render(hs.camera, q)
+        _, ost = pyoracle.render(hs.desc, hs.camera, hs.params)
+        assert s2.stats().rays == ost.rays and rays_fast <= ost.rays
+        same = (fast == exact) | (np.isnan(fast) & np.isnan(exact))
+        assert same.all()
+
+
+def test_replica_groups_forced(dev, monkeypatch):
+    """The per-sample radiance buffer is rendered in replica GROUPS when it exceeds its budget (BASELINE config C5
+    does: 69 GB against 64 GB).  Forced here with a zero budget: -t=3 becomes three groups of one replica, the
+    per-pixel accumulator carries the sums between groups (k_wf_resolve first_group / last_group) — the frame must
+    equal the single-group frame and the megakernel's bit for bit, and the oracle's at the f64 bar."""
+    hs = api.HostScene(["scenes/light_test", "-w=80", "-s=27", "-t=3", "--seed=19"])
+    assert hs.params.thread_count == 3 and hs.spp == 27
+    scene = api.DeviceScene(hs.desc, 0)
+    p = hs.params.copy()
+    p.pipeline = api.RT_PIPELINE_WAVEFRONT
+    one = scene.render(hs.camera, p)
+    assert scene.stats().n_replica_groups == 1
+    monkeypatch.setenv("RT_WF_SAMPLE_GB", "0")
+    three = scene.render(hs.camera, p)
+    assert scene.stats().n_replica_groups == 3
+    np.testing.assert_array_equal(three, one)
+    monkeypatch.setenv("RT_WF_POOL", "3000")       # pool smaller than one replica: regeneration inside every group
+    np.testing.assert_array_equal(scene.render(hs.camera, p), one)
+    assert scene.stats().n_replica_groups == 3
+    monkeypatch.delenv("RT_WF_POOL")
+    q = p.copy()
+    q.band_rows, q.n_parts, q.part = 16, 2, 1      # groups + row partition together
+    part = scene.render(hs.camera, q)
+    np.testing.assert_array_equal(part, one[api.owned_rows(hs.height, q)])
+    monkeypatch.delenv("RT_WF_SAMPLE_GB")
+    p.pipeline = api.RT_PIPELINE_MEGAKERNEL
+    np.testing.assert_array_equal(scene.render(hs.camera, p), one)
+    ref, _ = pyoracle.render(hs.desc, hs.camera, hs.params)
+    assert_f64_parity(one, ref)
 
 
 @pytest.mark.parametrize("name", sorted(GOLD.files))
@@ -286,6 +356,35 @@ def test_headline_config_rows_match_oracle(dev):
     q2.band_rows, q2.n_parts, q2.part = 1, 200, 123   # rows 123, 323, 523, 723, 923, 1123
     wider = scene.render(hs.camera, q2)
     np.testing.assert_array_equal(wider[[0, 2, 4]], gpu)
+
+
+def test_c5_config_rows_of_one_rank_match_oracle(dev):
+    """BASELINE.json's multi-GPU configuration C5 (cornell_dragon, 2400x2400, 4000 spp = 10 replicas x 20x20 strata,
+    frame row-tiled in 16-row bands over 8 GPUs), the share of rank 3.  (1) Two full rows of that share (1075 and
+    2227, bands 67 and 139: both 3 mod 8) against the oracle at the f64 bar.  (2) The rank's whole share exactly as
+    bench.py --gpus 8 renders it (band_rows 16, 8 parts, part 3: 304 rows, 2.9 G samples): its per-sample buffer
+    (70 GB) is over the 64 GB budget, so this is the replica-group path on the real configuration; the two rows cut
+    out of it must be the same bits."""
+    ensure_dragon()
+    hs = api.HostScene(["scenes/cornell_dragon", "-w=2400", "-s=4000", "-t=10", "--seed=1"])
+    assert (hs.width, hs.height, hs.spp) == (2400, 2400, 4000) and hs.params.sqrt_spt == 20 and hs.params.thread_count == 10
+    scene = api.DeviceScene(hs.desc, 0)
+    q = hs.params.copy()
+    q.band_rows, q.n_parts, q.part = 1, 1152, 1075
+    rows = api.owned_rows(hs.height, q)
+    assert list(rows) == [1075, 2227]
+    share = hs.params.copy()
+    share.band_rows, share.n_parts, share.part = 16, 8, 3
+    share_rows = api.owned_rows(hs.height, share)
+    assert len(share_rows) == 304 and all(r in share_rows for r in rows)
+    gpu = scene.render(hs.camera, q)
+    ref, st = pyoracle.render(hs.desc, hs.camera, q)
+    assert st.samples == 2 * 2400 * 4000
+    assert_f64_parity(gpu, ref)
+    full = scene.render(hs.camera, share)
+    assert full.shape == (304, 2400, 4)
+    assert scene.stats().n_replica_groups >= 2
+    np.testing.assert_array_equal(full[[share_rows.index(r) for r in rows]], gpu)
 
 
 @pytest.mark.parametrize("name", ["light_test", "default", "two_meshes", "texture_test"])
