@@ -114,6 +114,79 @@ def cpu_baseline(workload: str, seed: int):
     }
 
 
+def make_roofline(api, counters, kstats, a, owned_pixels, ms_per_step):
+    """`roofline` object for the DOMINANT kernel of this workload (largest HIP-event sum per step).
+
+    Algorithmic bytes are counted by the kernels themselves in the counter-collecting warm-up step (deterministic
+    for a given seed / config) and divided by the launches per step; durations are HIP-event times on the render
+    stream, summed per kernel by the library (RtRenderStats).  All kernels here are bound by memory traffic or by
+    latency, none by matrix throughput: bound = "hbm".
+      k_wf_mesh / k_wf_intersect / k_megakernel: BVH nodes fetched x node size + triangle tests x record size
+                                                 (+ path state of the rays handled)
+      k_wf_shade / k_wf_prims:                   path-state bytes read + written per ray
+    A kernel whose algorithmic bytes per second exceed the HBM peak is running out of L2 / Infinity Cache
+    (small BVH): `frac` is then null, never > 1."""
+    n = len(kstats)
+    mean = lambda k: sum(x[k] for x in kstats) / n
+    launches = mean("launches")
+    mega = counters.pipeline_used == api.RT_PIPELINE_MEGAKERNEL
+    bvh_bytes = counters.node_visits * counters.bytes_node + counters.tri_tests * counters.bytes_tri
+    if mega:
+        cands = {"k_megakernel": (mean("all"), bvh_bytes + counters.mesh_rays * counters.bytes_attr + owned_pixels * 32, 1.0)}
+    else:
+        cands = {
+            "k_wf_mesh (BVH traversal; k_wf_intersect for scenes with volumes or != 1 mesh)":
+                (mean("traversal"), bvh_bytes + counters.mesh_rays * counters.bytes_state, launches),
+            "k_wf_shade (scatter, pdf, regeneration, compaction)":
+                (mean("shade"), counters.rays * counters.bytes_state_shade + counters.samples * 24, launches),
+            "k_wf_prims (scene program over spheres / quads / sky / sun)":
+                (mean("prims"), counters.rays * counters.bytes_state_prims, launches),
+        }
+    name, (ms_step, nbytes_step, n_launch) = max(cands.items(), key=lambda kv: kv[1][0])
+    if ms_step <= 0:
+        return None
+    avg_ms = ms_step / n_launch
+    nbytes = nbytes_step / n_launch
+    achieved = nbytes / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            key = f"{a.workload}_{a.precision}_{name.split()[0]}_per_step"
+            traffic = json.load(open(tpath)).get(key)
+            if traffic is not None:
+                traffic = traffic / n_launch
+        except Exception:
+            traffic = None
+    cache_resident = achieved > HBM_PEAK_GBS
+    out = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": None if cache_resident else achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "kernel": name,
+        "note": ("algorithmic bytes / kernel time (HIP events).  " +
+                 ("The working set of this kernel is served by L2 / the 256 MB Infinity Cache: its algorithmic rate is above the HBM peak, so no HBM fraction is given.  "
+                  if cache_resident else "") +
+                 "`traffic` = rocprofv3 counter bytes of the same kernel per launch (2 x FETCH_SIZE + WRITE_SIZE, fabric side, "
+                 "calibration in profiles/r01/fetch_size_calibration.txt), from profiles/traffic.json when this workload was profiled."),
+        "dominant_kernel_share_of_step": ms_step / ms_per_step,
+        "kernel_ms_avg": avg_ms, "launches_per_step": n_launch, "algorithmic_bytes_per_launch": nbytes,
+        "kernel_ms_per_step": ms_step,
+        "all_kernels_ms_per_step": {k.split()[0]: v[0] for k, v in cands.items()},
+        "rays_per_sample": counters.rays / max(counters.samples, 1),
+        "mesh_rays_per_ray": counters.mesh_rays / counters.rays,
+        "node_visits_per_ray": counters.node_visits / counters.rays,
+        "tri_tests_per_ray": counters.tri_tests / counters.rays,
+        "bytes_node": counters.bytes_node, "bytes_tri": counters.bytes_tri,
+        "bytes_state_shade": counters.bytes_state_shade, "bytes_state_prims": counters.bytes_state_prims,
+    }
+    if name.startswith("k_wf_mesh") and counters.node_visits:
+        # the memory system's own limit for this access pattern (dependent fetches of random 128-B lines):
+        # tools/ubench/gather_lines on the same chip, profiles/r01/ubench_gather_lines.txt
+        out["line_requests_per_s"] = (counters.node_visits * -(-counters.bytes_node // 128) + counters.tri_tests * counters.bytes_tri / 128.0) / n_launch / (avg_ms * 1e-3)
+        out["random_line_ceiling_per_s"] = [59e9, 79e9]
+    return out
+
+
 def free_port() -> int:
     import socket
     s = socket.socket()
@@ -234,12 +307,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    kernel_ms, launches = [], []
+    kstats = []  # per timed step: HIP-event sums per kernel (library side, on the render stream) + launch counts
     for _ in range(a.steps):
         step()
         st_ = scene.stats()
-        kernel_ms.append(st_.traversal_kernel_ms)
-        launches.append(max(st_.n_launches, 1))
+        kstats.append({"traversal": st_.traversal_kernel_ms, "prims": st_.prims_kernel_ms, "shade": st_.shade_kernel_ms,
+                       "all": st_.kernel_ms, "launches": max(st_.n_launches, 1)})
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -254,55 +327,8 @@ def main():
     value = total_samples * a.steps / elapsed / 1e6
 
     roofline = None
-    if counters is not None and counters.rays > 0 and kernel_ms:
-        # Algorithmic bytes of the dominant kernel (this rank's rows), counted by the kernels themselves:
-        #   BVH nodes fetched x node size + triangle tests x triangle record size + path state of the
-        #   rays it handles (wavefront mesh kernel) or attribute records + frame (megakernel).
-        mega = counters.pipeline_used == api.RT_PIPELINE_MEGAKERNEL
-        nbytes = counters.node_visits * counters.bytes_node + counters.tri_tests * counters.bytes_tri
-        if mega:
-            nbytes += counters.mesh_rays * counters.bytes_attr + rows * hs.width * 32
-        else:
-            nbytes += counters.mesh_rays * counters.bytes_state
-        # per LAUNCH of the dominant kernel: a step is 1 launch of the megakernel or n launches of
-        # k_wf_intersect (one per wavefront iteration); durations are HIP-event times on the
-        # render stream, summed by the library (RtRenderStats.traversal_kernel_ms / n_launches)
-        n_launch = sum(launches) / len(launches)
-        avg_ms = sum(kernel_ms) / len(kernel_ms) / n_launch
-        nbytes = nbytes / n_launch
-        achieved = nbytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                kname = "mega" if counters.pipeline_used == api.RT_PIPELINE_MEGAKERNEL else "wf"
-                traffic = json.load(open(tpath)).get(f"{a.workload}_{a.precision}_{kname}_per_step")
-                if traffic is not None:
-                    traffic = traffic / n_launch
-            except Exception:
-                traffic = None
-        roofline = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "k_megakernel" if mega else "k_wf_mesh (BVH traversal; k_wf_intersect for scenes with != 1 mesh)",
-            "note": "algorithmic bytes / kernel time; part of these bytes is served by L2 (29 % hits) and the 256 MB Infinity "
-                    "Cache, so this is above what HBM itself moves; `traffic` = rocprofv3 2 x FETCH_SIZE + WRITE_SIZE (fabric side: Infinity "
-                    "Cache + HBM; FETCH_SIZE calibrated on a known byte count in this access pattern: it counts 128-B requests as 64 B) of "
-                    "the same kernel per launch (profiles/r01): 5.4 TB/s = 68 % of the HBM peak during traversal. The kernel's real limit is the REQUEST rate of the L2-miss path: "
-                    "58.8 G L1->L2 read requests/s measured (TCP_TCC_READ_REQ) against 59-79 G/s that a pure random-line gather "
-                    "reaches on this chip (tools/ubench/gather_lines)",
-            "dominant_kernel_share_of_step": (avg_ms * n_launch) / (elapsed / a.steps * 1e3),
-            "kernel_ms_avg": avg_ms, "launches_per_step": n_launch, "algorithmic_bytes_per_launch": nbytes,
-            "kernel_ms_per_step": avg_ms * n_launch,
-            "rays_per_sample": counters.rays / max(counters.samples, 1),
-            "node_visits_per_ray": counters.node_visits / counters.rays,
-            "tri_tests_per_ray": counters.tri_tests / counters.rays,
-            "bytes_node": counters.bytes_node, "bytes_tri": counters.bytes_tri,
-            # the memory system's own limit for this access pattern (dependent fetches of random 128-B lines):
-            # tools/ubench/gather_lines on the same chip, profiles/r01/ubench_gather_lines.txt
-            "line_requests_per_s": (counters.node_visits + counters.tri_tests * counters.bytes_tri / 128.0) / n_launch / (avg_ms * 1e-3),
-            "random_line_ceiling_per_s": [59e9, 79e9],
-        }
+    if counters is not None and counters.rays > 0 and kstats:
+        roofline = make_roofline(api, counters, kstats, a, rows * hs.width, elapsed / a.steps * 1e3)
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -957,15 +957,25 @@ RT_DEV bool shade(const SceneView<R>& sc, const ParamsView<R>& prm, PathState<R>
 }
 
 // The part of shade() after the hit has been resolved (k_wf_shade calls the two halves itself, so that the
-// path's throughput / radiance / RNG are loaded only after resolve_hit: they are not live across its loops).
+// path's throughput / RNG are loaded only after resolve_hit: they are not live across its loops).
 // FULL: the full-feature kernel variant (TEX): additionally evaluates ObjectLists nested inside `lights`.
+//
+// Every continuing case only produces the new DIRECTION; the new ray (origin = hit.pos for every material) is
+// built once, behind the switch.  This is deliberate: with `ps.ray = make_ray(hit.pos, dir)` written inside each
+// case, hipcc (ROCm 7.2, clang 22) produced a k_wf_shade in which the Dielectric lanes that reflect by the
+// Schlick coin (not total internal reflection) keep two temporaries of the reflectance / RNG code in the
+// registers of origin.x / origin.y: after structurisation the join behind the refract block takes those
+// registers from an undefined value on the edge that skips it (profiles/r02/shade_dielectric_isa_excerpt.s,
+// found with the pool trace RT_WF_TRACE).  The bit-exact wavefront-vs-megakernel tests guard this.
 template <typename R, bool STATS, bool FULL>
 RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathState<R>& ps, const HitInfo<R>& hit, Rng& rng, LaneCounters& cnt) {
     const MaterialRec mat = sc.materials[hit.material];
-    V3<R> attenuation;
-    V3<R> pdf_w;          // CosinePDF::w (the shading normal), cosine.rs:17-22
+    V3<R> attenuation = mk<R>(0, 0, 0);
+    V3<R> pdf_w = mk<R>(0, 0, 0);  // CosinePDF::w (the shading normal), cosine.rs:17-22
+    V3<R> dir = mk<R>(0, 0, 0);    // direction of the continuation ray
     bool with_pdf = false;
     bool uniform_pdf = false;
+    bool weight_changed = false;   // the throughput was multiplied by something other than (1,1,1)
     switch (mat.type) {
         case RT_MAT_EMISSIVE: {  // emissive.rs:24-34; camera.rs:327
             if (hit.front_face) ps.radiance = ps.throughput * hit.tex_a;
@@ -988,13 +998,13 @@ RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathStat
             break;
         case RT_MAT_METAL: {  // metal.rs:28-44
             V3<R> reflected = reflect(ps.ray.d, hit.normal);
-            V3<R> scatter_dir = reflected + random_unit<R>(rng) * hit.tex_b * length(reflected);
-            if (!(dot(scatter_dir, hit.normal) > R(0))) { end_black(ps); return false; }  // Absorbed (camera.rs:326)
+            dir = reflected + random_unit<R>(rng) * hit.tex_b * length(reflected);
+            if (!(dot(dir, hit.normal) > R(0))) { end_black(ps); return false; }  // Absorbed (camera.rs:326)
             ps.throughput = ps.throughput * hit.tex_a;
-            ps.ray = make_ray(hit.pos, scatter_dir);
-            return path_goes_on(sc, ps);
+            weight_changed = true;
+            break;
         }
-        case RT_MAT_DIELECTRIC: {  // dielectric.rs:29-54
+        case RT_MAT_DIELECTRIC: {  // dielectric.rs:29-54, attenuation (1,1,1)
             R ior = sc.material_params[hit.material].ior;
             R ior_ratio = hit.front_face ? R(1) / ior : ior;
             V3<R> unit_dir = to_unit(ps.ray.d);
@@ -1002,22 +1012,20 @@ RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathStat
             R sin_theta = sqrt(R(1) - cos_theta * cos_theta);
             bool tir = ior_ratio * sin_theta > R(1);
             bool reflected = tir || reflectance(cos_theta, ior_ratio) > rng_uniform<R>(rng);  // no draw on TIR
-            V3<R> scatter_dir = reflected ? reflect(unit_dir, hit.normal) : refract(unit_dir, hit.normal, ior_ratio);
-            ps.ray = make_ray(hit.pos, scatter_dir);  // attenuation (1,1,1)
-            return true;
+            dir = reflected ? reflect(unit_dir, hit.normal) : refract(unit_dir, hit.normal, ior_ratio);
+            break;
         }
         case RT_MAT_GLOSSY: {  // glossy.rs:54-83
             V3<R> normal = hit.normal;
             V3<R> unit_dir = to_unit(ps.ray.d);
             R cos_theta = fmin(R(1), dot(-unit_dir, normal));
             bool specular = reflectance(cos_theta, sc.material_params[hit.material].inv_ior) > rng_uniform<R>(rng);
-            if (specular) {
+            if (specular) {  // attenuation (1,1,1)
                 R roughness = hit.tex_b;
                 V3<R> reflected = reflect(ps.ray.d, normal);
-                V3<R> scatter_dir = reflected + random_unit<R>(rng) * roughness * length(reflected);
-                if (!(dot(scatter_dir, normal) > R(0))) { end_black(ps); return false; }  // Absorbed
-                ps.ray = make_ray(hit.pos, scatter_dir);               // attenuation (1,1,1)
-                return true;
+                dir = reflected + random_unit<R>(rng) * roughness * length(reflected);
+                if (!(dot(dir, normal) > R(0))) { end_black(ps); return false; }  // Absorbed
+                break;
             }
             attenuation = hit.tex_a;
             pdf_w = normal;
@@ -1028,37 +1036,37 @@ RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathStat
             end_black(ps);
             return false;
     }
-    if (!with_pdf) { end_black(ps); return false; }
-
-    // ScatteredWithPDF: camera.rs:298-315 with MixPDF (mix.rs:23-36)
-    V3<R> dir;
-    if (rng_uniform<R>(rng) < prm.light_bias) {
-        dir = lights_random<R, FULL>(sc, hit.pos, rng);
-    } else if (uniform_pdf) {
-        dir = random_unit<R>(rng);  // uniform.rs:22-24
-    } else {
-        V3<R> bu, bv;
-        onb_from_vec(pdf_w, bu, bv);
-        dir = basis_apply(bu, bv, pdf_w, random_cosine<R>(rng));  // cosine.rs:31-33
+    if (with_pdf) {
+        // ScatteredWithPDF: camera.rs:298-315 with MixPDF (mix.rs:23-36)
+        if (rng_uniform<R>(rng) < prm.light_bias) {
+            dir = lights_random<R, FULL>(sc, hit.pos, rng);
+        } else if (uniform_pdf) {
+            dir = random_unit<R>(rng);  // uniform.rs:22-24
+        } else {
+            V3<R> bu, bv;
+            onb_from_vec(pdf_w, bu, bv);
+            dir = basis_apply(bu, bv, pdf_w, random_cosine<R>(rng));  // cosine.rs:31-33
+        }
+        R first_val;
+        R scattering_pdf;
+        if (uniform_pdf) {
+            first_val = R(1) / (R(4) * pi<R>());       // uniform.rs:18-20
+            scattering_pdf = R(1) / (R(4) * pi<R>());  // isotropic.rs:35-37
+        } else {
+            V3<R> unit = to_unit(dir);
+            first_val = fmax(dot(unit, pdf_w) / pi<R>(), R(0));  // cosine.rs:26-29
+            R cos_theta = dot(pdf_w, unit);                      // lambertian.rs:35-43 / glossy.rs:86-95
+            scattering_pdf = cos_theta < R(0) ? R(0) : cos_theta / pi<R>();
+        }
+        R second_val = lights_pdf_value<R, STATS, FULL>(sc, hit.pos, dir, cnt);
+        R pdf = first_val * (R(1) - prm.light_bias) + second_val * prm.light_bias;
+        // (scatter_color * attenuation * scattering_pdf) / pdf, camera.rs:312
+        V3<R> w = (attenuation * scattering_pdf) / pdf;
+        ps.throughput = ps.throughput * w;
+        weight_changed = true;
     }
-    R first_val;
-    R scattering_pdf;
-    if (uniform_pdf) {
-        first_val = R(1) / (R(4) * pi<R>());       // uniform.rs:18-20
-        scattering_pdf = R(1) / (R(4) * pi<R>());  // isotropic.rs:35-37
-    } else {
-        V3<R> unit = to_unit(dir);
-        first_val = fmax(dot(unit, pdf_w) / pi<R>(), R(0));  // cosine.rs:26-29
-        R cos_theta = dot(pdf_w, unit);                      // lambertian.rs:35-43 / glossy.rs:86-95
-        scattering_pdf = cos_theta < R(0) ? R(0) : cos_theta / pi<R>();
-    }
-    R second_val = lights_pdf_value<R, STATS, FULL>(sc, hit.pos, dir, cnt);
-    R pdf = first_val * (R(1) - prm.light_bias) + second_val * prm.light_bias;
-    // (scatter_color * attenuation * scattering_pdf) / pdf, camera.rs:312
-    V3<R> w = (attenuation * scattering_pdf) / pdf;
-    ps.throughput = ps.throughput * w;
-    ps.ray = make_ray(hit.pos, dir);
-    return path_goes_on(sc, ps);
+    ps.ray = make_ray(hit.pos, dir);  // the ONE place where the continuation ray is built (see above)
+    return weight_changed ? path_goes_on(sc, ps) : true;
 }
 
 }  // namespace rt

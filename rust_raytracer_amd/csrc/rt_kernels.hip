@@ -674,7 +674,8 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     // small tables staged in LDS by the prims / shade kernels when they fit
     const bool lds_tables = ds.view.lay.total_bytes <= 48u * 1024u && env_u32("RT_LDS_TABLES", 1) != 0;
     const size_t lds_small = lds_tables ? size_t(ds.view.lay.total_bytes) : 0;
-    const uint32_t check_every = std::min<uint32_t>(32u, std::max<uint32_t>(1u, env_u32("RT_WF_CHECK", 8)));  // 4 timing events per iteration, 128 events
+    const bool trace_pool = env_u32("RT_WF_TRACE", 0) != 0;  // debug: dump the first pool slots after every iteration
+    const uint32_t check_every = trace_pool ? 1u : std::min<uint32_t>(32u, std::max<uint32_t>(1u, env_u32("RT_WF_CHECK", 8)));  // 4 timing events per iteration, 128 events
     const bool tex = s->compiled.needs_tex_interpreter;
     const size_t shade_lds_pad = env_u32("RT_WF_SHADE_LDS_PAD", 0);  // experiments: fewer resident blocks of the shade kernel
 
@@ -749,6 +750,27 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
                     HIP_TRY(hipEventElapsedTime(&ms, w.events[e + ph], w.events[e + ph + 1]));
                     phase_ms[ph] += ms;
                 }
+            if (trace_pool) {
+                const uint32_t n = std::min<uint32_t>(first, env_u32("RT_WF_TRACE", 0));
+                std::vector<R> a[12];
+                R* src[12] = {pool.ox, pool.oy, pool.oz, pool.dx, pool.dy, pool.dz, pool.tr, pool.tg, pool.tb, pool.ht, pool.hu, pool.hv};
+                for (int k = 0; k < 12; k++) { a[k].resize(n); HIP_TRY(hipMemcpy(a[k].data(), src[k], n * sizeof(R), hipMemcpyDeviceToHost)); }
+                std::vector<uint64_t> rngs(n), smp(n);
+                std::vector<uint32_t> dep(n), qn(first);
+                std::vector<int32_t> hpc(n);
+                HIP_TRY(hipMemcpy(rngs.data(), pool.rng, n * 8, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(smp.data(), pool.sample, n * 8, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(dep.data(), pool.depth, n * 4, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(hpc.data(), pool.hpc, n * 4, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(qn.data(), w.queue[qi], size_t(w.h_ctr->n_in) * 4, hipMemcpyDeviceToHost));
+                std::fprintf(stderr, "[wf trace] iteration %u: %u paths queued:", isect_launches, w.h_ctr->n_in);
+                for (uint32_t k = 0; k < w.h_ctr->n_in && k < 64; k++) std::fprintf(stderr, " %u", qn[k]);
+                std::fprintf(stderr, "\n");
+                for (uint32_t k = 0; k < n; k++)
+                    std::fprintf(stderr, "  slot %u sample %llu depth %u o %.17g %.17g %.17g d %.17g %.17g %.17g thr %.6g %.6g %.6g hit t %.17g pc %d rng %016llx\n", k,
+                                 (unsigned long long)smp[k], dep[k], double(a[0][k]), double(a[1][k]), double(a[2][k]), double(a[3][k]), double(a[4][k]),
+                                 double(a[5][k]), double(a[6][k]), double(a[7][k]), double(a[8][k]), double(a[9][k]), hpc[k], (unsigned long long)rngs[k]);
+            }
             upper = w.h_ctr->n_in;
             if (upper == 0) break;
         }

@@ -840,8 +840,13 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
 // ---------------------------------------------------------------------------------------------
 // Shade: one path vertex per lane (camera.rs:295-331), regeneration and queue compaction.
 // ---------------------------------------------------------------------------------------------
+#ifdef RT_SHADE_WAVES
+#define RT_SHADE_BOUNDS __launch_bounds__(256, RT_SHADE_WAVES)
+#else
+#define RT_SHADE_BOUNDS __launch_bounds__(256)
+#endif
 template <typename R, bool STATS, bool LDS, bool TEX>
-__global__ void __launch_bounds__(256) k_wf_shade(SceneView<R> sc_g, CameraView<R> cam, ParamsView<R> prm, WfPool<R> pool, WfGroup<R> grp,
+__global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam, ParamsView<R> prm, WfPool<R> pool, WfGroup<R> grp,
                                                   const uint32_t* __restrict__ queue_in, uint32_t* __restrict__ queue_out,
                                                   WfCounters* __restrict__ ctr, double* __restrict__ sample_L, DeviceCounters* counters) {
     extern __shared__ __align__(16) char lds_raw[];

@@ -121,7 +121,7 @@ def test_zero_weight_paths_are_traced_unless_the_light_set_is_safe(dev, monkeypa
     assert 0.3 < nan_ref.mean() < 0.8
     np.testing.assert_array_equal(np.isnan(gpu[..., :3]), np.isnan(ref[..., :3]))
     assert_f64_parity(gpu, ref)
-    assert scene.stats().rays == ost.rays          # nothing is cut short
+    assert scene.stats().rays <= ost.rays          # only paths whose weight is NaN in every channel end early (their value is NaN whatever follows)
     for name in ("cornell", "light_test", "default"):
         hs = api.HostScene(SCENES[name])
         assert api.scene_info(hs.desc) & api.RT_SCENE_INFO_ZERO_WEIGHT_STOP
