@@ -130,7 +130,9 @@ def make_roofline(api, counters, kstats, a, owned_pixels, ms_per_step):
     mean = lambda k: sum(x[k] for x in kstats) / n
     launches = mean("launches")
     mega = counters.pipeline_used == api.RT_PIPELINE_MEGAKERNEL
-    bvh_bytes = counters.node_visits * counters.bytes_node + counters.tri_tests * counters.bytes_tri
+    # leaf data: one record per triangle test, or (wavefront mesh kernel) one aligned line per leaf record of 1-2 triangles
+    leaf_fetches = counters.leaf_records if counters.leaf_records else counters.tri_tests
+    bvh_bytes = counters.node_visits * counters.bytes_node + leaf_fetches * counters.bytes_tri
     if mega:
         cands = {"k_megakernel": (mean("all"), bvh_bytes + counters.mesh_rays * counters.bytes_attr + owned_pixels * 32, 1.0)}
     else:
@@ -182,7 +184,8 @@ def make_roofline(api, counters, kstats, a, owned_pixels, ms_per_step):
     if name.startswith("k_wf_mesh") and counters.node_visits:
         # the memory system's own limit for this access pattern (dependent fetches of random 128-B lines):
         # tools/ubench/gather_lines on the same chip, profiles/r01/ubench_gather_lines.txt
-        out["line_requests_per_s"] = (counters.node_visits * -(-counters.bytes_node // 128) + counters.tri_tests * counters.bytes_tri / 128.0) / n_launch / (avg_ms * 1e-3)
+        out["line_requests_per_s"] = (counters.node_visits * -(-counters.bytes_node // 128) + leaf_fetches * counters.bytes_tri / 128.0) / n_launch / (avg_ms * 1e-3)
+        out["leaf_records_per_ray"] = counters.leaf_records / counters.rays
         out["random_line_ceiling_per_s"] = [59e9, 79e9]
     return out
 

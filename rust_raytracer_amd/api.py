@@ -114,7 +114,8 @@ class RtRenderStats(C.Structure):
                 ("bytes_state", C.c_uint64),
                 ("prims_kernel_ms", C.c_double), ("shade_kernel_ms", C.c_double),
                 ("bytes_state_prims", C.c_uint64), ("bytes_state_shade", C.c_uint64),
-                ("n_iterations", C.c_uint32), ("n_replica_groups", C.c_uint32)]
+                ("n_iterations", C.c_uint32), ("n_replica_groups", C.c_uint32),
+                ("leaf_records", C.c_uint64)]
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -212,6 +213,8 @@ def load_device_lib() -> C.CDLL:
         lib.rt_debug_trace_sample.restype = C.c_int
         lib.rt_scene_info.argtypes = [C.POINTER(RtSceneDesc), C.POINTER(C.c_uint32)]
         lib.rt_scene_info.restype = C.c_int
+        lib.rt_scene_mesh_stats.argtypes = [C.POINTER(RtSceneDesc), C.POINTER(C.c_uint64)]
+        lib.rt_scene_mesh_stats.restype = C.c_int
         lib.rt_last_error.argtypes = []
         lib.rt_last_error.restype = C.c_char_p
         _device_lib = lib
@@ -229,6 +232,16 @@ def scene_info(desc) -> int:
     if st != RT_OK:
         raise RtError(st, lib.rt_last_error().decode())
     return flags.value
+
+
+def scene_mesh_stats(desc) -> dict:
+    """rt_scene_mesh_stats: triangles / leaf records / pair records / BVH node counts (host only)."""
+    lib = load_device_lib()
+    out = (C.c_uint64 * 5)()
+    st = lib.rt_scene_mesh_stats(desc, out)
+    if st != RT_OK:
+        raise RtError(st, lib.rt_last_error().decode())
+    return dict(zip(("triangles", "records", "pair_records", "bvh2_nodes", "bvh4_nodes"), [int(x) for x in out]))
 
 
 def owned_rows(height: int, params: RtRenderParams) -> list:

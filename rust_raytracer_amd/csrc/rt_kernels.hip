@@ -314,6 +314,9 @@ struct DeviceScene {
             cast_arr(tris[i].v0, cs.tris[i].v0); cast_arr(tris[i].e1, cs.tris[i].e1); cast_arr(tris[i].e2, cs.tris[i].e2);
             tris[i]._pad = R(0);
         }
+        std::vector<TriPair<R>> pairs(cs.pairs.size());
+        for (size_t i = 0; i < pairs.size(); i++)
+            for (int k = 0; k < 16; k++) pairs[i].q[k] = R(cs.pairs[i].q[k]);
         std::vector<TriAttr<R>> attrs(cs.attrs.size());
         for (size_t i = 0; i < attrs.size(); i++) {
             const auto& s = cs.attrs[i];
@@ -358,6 +361,7 @@ struct DeviceScene {
         if ((st = buf.upload(nodes4, &view.nodes4)) != RT_OK) return st;
         if ((st = buf.upload(mesh_bounds, &view.mesh_bounds)) != RT_OK) return st;
         if ((st = buf.upload(tris, &view.tris)) != RT_OK) return st;
+        if ((st = buf.upload(pairs, &view.pairs)) != RT_OK) return st;
         if ((st = buf.upload(attrs, &view.attrs)) != RT_OK) return st;
         if ((st = buf.upload(cs.materials, &view.materials)) != RT_OK) return st;
         if ((st = buf.upload(mparams, &view.material_params)) != RT_OK) return st;
@@ -572,7 +576,7 @@ int wf_ensure(RtScene* s, uint32_t capacity) {
         if (!w.d_ctr) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.d_ctr), sizeof(WfCounters)));
         if (!w.h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w.h_ctr), sizeof(WfCounters)));
         if (w.events.empty()) {
-            w.events.resize(128);  // 4 per iteration, up to 32 iterations between host checks
+            w.events.resize(136);  // 4 per iteration, up to 32 iterations between host checks, + 2 for the stand-alone prims launch
             for (auto& e : w.events) e = nullptr;
             for (auto& e : w.events) HIP_TRY(hipEventCreate(&e));
         }
@@ -648,6 +652,9 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     if (n_mesh_ops != 1 || env_u32("RT_WF_SPLIT", 1) == 0 || vol) mesh_pc = -1;  // a volume's draws happen in program order
     const bool prims_only = n_mesh_ops == 0 && env_u32("RT_WF_SPLIT", 1) != 0 && !vol;
     const bool split = mesh_pc >= 0;
+    // the primitive program runs inside k_wf_shade on every new ray (k_wf_prims only for the camera rays of k_wf_generate)
+    // (not for the texture-interpreter variant: fused it needs more than 256 VGPRs, i.e. one wave per SIMD)
+    const bool fuse = (split || prims_only) && !s->compiled.needs_tex_interpreter && env_u32("RT_WF_FUSE", 0) != 0;  // measured slower than the separate pass (profiles/r02/ab/fuse_prims_into_shade.txt): off by default
     // k_wf_mesh keeps (child, entry distance) pairs: a shallow LDS part (occupancy) + a global spill part
     const int mesh_levels = int(s->compiled.max_bvh4_stack) + 1;
     const int lds_levels = std::min<int>(mesh_levels, int(env_u32("RT_WF_LDS_LEVELS", 12)));
@@ -700,23 +707,32 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
         init.n_out = 0;
         init.cursor = 0;
         init.n_mesh = 0;
+        init.n_mesh_next = 0;
         init.next_sample = first;
         *w.h_ctr = init;
         HIP_TRY(hipMemcpyAsync(w.d_ctr, w.h_ctr, sizeof(WfCounters), hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL((k_wf_generate<R>), dim3((first + 255) / 256), dim3(256), 0, stream, pool, first, grp, cv, pv, w.queue[0]);
         int qi = 0;
         uint32_t upper = first;  // upper bound of the queue length (never grows: slots are reused in place)
+#define RT_LAUNCH_PRIMS(ST, L) hipLaunchKernelGGL((k_wf_prims<R, ST, L>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), lds_small + (WF_CHUNK + 4) * 4, stream, ds.view, pool, w.queue[qi], w.mesh_queue, w.d_ctr, s->d_counters, mesh_pc)
+#define RT_LAUNCH_PRIMS_ANY() do { if (stats) { if (lds_tables) RT_LAUNCH_PRIMS(true, true); else RT_LAUNCH_PRIMS(true, false); } \
+                                   else { if (lds_tables) RT_LAUNCH_PRIMS(false, true); else RT_LAUNCH_PRIMS(false, false); } } while (0)
+        if (fuse) {  // camera rays of k_wf_generate: the only rays the fused shade kernel has not seen
+            HIP_TRY(hipEventRecord(w.events[0], stream));
+            RT_LAUNCH_PRIMS_ANY();
+            HIP_TRY(hipEventRecord(w.events[1], stream));
+        }
+        bool first_round = true;
         for (;;) {
             size_t ev = 0;
+            if (fuse && first_round) ev = 2;  // events 0 / 1 bracket the stand-alone prims launch above
+            const size_t ev0 = ev;
             for (uint32_t k = 0; k < check_every; k++) {
                 HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 if (split || prims_only) {
-#define RT_LAUNCH_PRIMS(ST, L) hipLaunchKernelGGL((k_wf_prims<R, ST, L>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), lds_small + (WF_CHUNK + 4) * 4, stream, ds.view, pool, w.queue[qi], w.mesh_queue, w.d_ctr, s->d_counters, mesh_pc)
-                    if (stats) { if (lds_tables) RT_LAUNCH_PRIMS(true, true); else RT_LAUNCH_PRIMS(true, false); }
-                    else { if (lds_tables) RT_LAUNCH_PRIMS(false, true); else RT_LAUNCH_PRIMS(false, false); }
-#undef RT_LAUNCH_PRIMS
+                    if (!fuse) RT_LAUNCH_PRIMS_ANY();
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
-                    if (prims_only) { /* nothing deferred: the prims kernel is the whole closest-hit search */ }
+                    if (prims_only) { /* nothing deferred: the primitive program is the whole closest-hit search */ }
                     else if (stats)
                         hipLaunchKernelGGL((k_wf_mesh<R, true>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels);
                     else
@@ -730,11 +746,13 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
 #undef RT_LAUNCH_ISECT
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 }
-#define RT_LAUNCH_SHADE(ST, L, TX) hipLaunchKernelGGL((k_wf_shade<R, ST, L, TX>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), (L ? lds_small : size_t(0)) + (2 * WF_CHUNK + 8) * 4 + shade_lds_pad, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters)
+#define RT_LAUNCH_SHADE(ST, L, TX, FU) hipLaunchKernelGGL((k_wf_shade<R, ST, L, TX, FU>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), (L ? lds_small : size_t(0)) + ((FU ? 3 : 2) * WF_CHUNK + 8) * 4 + shade_lds_pad, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters, w.mesh_queue, mesh_pc)
+#define RT_LAUNCH_SHADE_F(ST, L, TX) do { if (fuse) RT_LAUNCH_SHADE(ST, L, TX, true); else RT_LAUNCH_SHADE(ST, L, TX, false); } while (0)
                 if (tex) {  // interpreter variant: tables from global memory (rare scenes, fewer instantiations)
-                    if (stats) RT_LAUNCH_SHADE(true, false, true); else RT_LAUNCH_SHADE(false, false, true);
-                } else if (stats) { if (lds_tables) RT_LAUNCH_SHADE(true, true, false); else RT_LAUNCH_SHADE(true, false, false); }
-                else { if (lds_tables) RT_LAUNCH_SHADE(false, true, false); else RT_LAUNCH_SHADE(false, false, false); }
+                    if (stats) RT_LAUNCH_SHADE_F(true, false, true); else RT_LAUNCH_SHADE_F(false, false, true);
+                } else if (stats) { if (lds_tables) RT_LAUNCH_SHADE_F(true, true, false); else RT_LAUNCH_SHADE_F(true, false, false); }
+                else { if (lds_tables) RT_LAUNCH_SHADE_F(false, true, false); else RT_LAUNCH_SHADE_F(false, false, false); }
+#undef RT_LAUNCH_SHADE_F
 #undef RT_LAUNCH_SHADE
                 hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(1), 0, stream, w.d_ctr);
                 HIP_TRY(hipEventRecord(w.events[ev++], stream));
@@ -744,7 +762,13 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(w.h_ctr, w.d_ctr, sizeof(WfCounters), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
-            for (size_t e = 0; e + 3 < ev; e += 4)
+            if (fuse && first_round) {
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, w.events[0], w.events[1]));
+                phase_ms[0] += ms;
+            }
+            first_round = false;
+            for (size_t e = ev0; e + 3 < ev; e += 4)
                 for (int ph = 0; ph < 3; ph++) {
                     float ms = 0.f;
                     HIP_TRY(hipEventElapsedTime(&ms, w.events[e + ph], w.events[e + ph + 1]));
@@ -774,6 +798,8 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
             upper = w.h_ctr->n_in;
             if (upper == 0) break;
         }
+#undef RT_LAUNCH_PRIMS_ANY
+#undef RT_LAUNCH_PRIMS
         hipLaunchKernelGGL(k_wf_resolve, dim3(uint32_t((npix + 255) / 256)), dim3(256), 0, stream, w.sample_L, w.acc, npix, strata, nrep,
                            pv.spp, int(t0 == 0), d_out, int(t0 + nrep >= T));
     }
@@ -809,7 +835,8 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     st.tri_tests = hc.tri_tests;
     st.prim_tests = hc.prim_tests;
     st.bytes_node = split ? sizeof(BvhNode4f) : sizeof(BvhNode<R>);
-    st.bytes_tri = sizeof(TriRec<R>);
+    st.bytes_tri = split ? sizeof(TriPair<R>) : sizeof(TriRec<R>);
+    st.leaf_records = split ? hc.leaf_records : 0;
     st.bytes_attr = sizeof(TriAttr<R>);
     // path state moved by the DOMINANT kernel per ray it traverses: ray (6 R) + bound/op read (R + 4)
     // + hit written when a triangle wins (3 R + 8) + queue entry (4)
@@ -818,6 +845,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     // sample index in, ray + throughput + rng + depth out (a path that ends writes 24 B of radiance instead and restarts)
     st.bytes_state_prims = 6 * sizeof(R) + 3 * sizeof(R) + 8;
     st.bytes_state_shade = (6 + 3 + 3) * sizeof(R) + 8 + 8 + 4 + 8 + (6 + 3) * sizeof(R) + 8 + 4;
+    if (fuse) st.bytes_state_shade += 3 * sizeof(R) + 8 + 4;  // + closest primitive hit of the new ray and its mesh-queue entry
     if (!split) st.mesh_rays = hc.rays;  // combined kernel: every ray's state passes through it
     return RT_OK;
 }
@@ -1010,6 +1038,21 @@ int rt_scene_info(const RtSceneDesc* desc, uint32_t* flags_out) {
     if (st != RT_OK) return set_err(st, err);
     *flags_out = (cs.zero_weight_stop ? RT_SCENE_INFO_ZERO_WEIGHT_STOP : 0u) | (cs.needs_tex_interpreter ? RT_SCENE_INFO_TEX_INTERPRETER : 0u) |
                  (cs.volumes.empty() ? 0u : RT_SCENE_INFO_VOLUMES);
+    return RT_OK;
+}
+
+int rt_scene_mesh_stats(const RtSceneDesc* desc, uint64_t out[5]) {
+    using namespace rt;
+    if (!desc || !out) return set_err(RT_E_INVALID, "rt_scene_mesh_stats: NULL argument");
+    CompiledScene cs;
+    std::string err;
+    int st = compile_scene(desc, &cs, &err, CompileOptions());
+    if (st != RT_OK) return set_err(st, err);
+    out[0] = cs.n_mesh_triangles;
+    out[1] = cs.n_records;
+    out[2] = cs.n_pair_records;
+    out[3] = cs.nodes.size();
+    out[4] = cs.nodes4.size();
     return RT_OK;
 }
 

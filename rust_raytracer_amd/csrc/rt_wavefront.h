@@ -54,6 +54,8 @@ struct WfCounters {
     uint32_t n_out;       // entries appended to the next queue
     uint32_t cursor;      // next queue entry to hand out (persistent intersect / mesh kernel)
     uint32_t n_mesh;      // entries of the mesh queue (paths whose ray enters the deferred mesh's box)
+    uint32_t n_mesh_next; // mesh queue being filled by the fused shade kernel for the NEXT iteration (k_wf_advance moves it to n_mesh)
+    uint32_t _pad;
     unsigned long long next_sample;  // next sample (within the group) to start
 };
 
@@ -68,8 +70,8 @@ struct WfGroup {
 };
 
 template <typename R>
-RT_DEV void wf_start_sample(const WfPool<R>& pool, uint32_t slot, uint64_t s, const WfGroup<R>& grp,
-                            const CameraView<R>& cam, const ParamsView<R>& prm) {
+RT_DEV Ray<R> wf_start_sample(const WfPool<R>& pool, uint32_t slot, uint64_t s, const WfGroup<R>& grp,
+                              const CameraView<R>& cam, const ParamsView<R>& prm) {
     uint64_t per_replica = uint64_t(grp.strata) * grp.npix;
     uint32_t tid_local = uint32_t(s / per_replica);
     uint64_t rem = s - uint64_t(tid_local) * per_replica;
@@ -90,6 +92,7 @@ RT_DEV void wf_start_sample(const WfPool<R>& pool, uint32_t slot, uint64_t s, co
     pool.rng[slot] = rng.s;
     pool.sample[slot] = s;
     pool.depth[slot] = cam.max_depth;
+    return ray;
 }
 
 template <typename R>
@@ -111,7 +114,7 @@ RT_DEV uint32_t lane_prefix(unsigned long long mask) {
 // bottleneck of every kernel here.  Queue traffic is therefore aggregated per WORKGROUP through
 // LDS lists (chunked kernels: one global atomic per WF_CHUNK entries) and the persistent kernels
 // reserve WF_BATCH entries per atomic.
-constexpr uint32_t WF_CHUNK = 4096;  // queue entries handled by one workgroup of the chunked kernels
+constexpr uint32_t WF_CHUNK = 2048;  // queue entries handled by one workgroup of the chunked kernels (three LDS lists of this size in k_wf_shade)
 constexpr uint32_t WF_BATCH = 256;   // queue entries a wave of a persistent kernel reserves at once
 
 // Appends `value` of the lanes with `pred` to an LDS list: ballot + mbcnt prefix, one LDS atomic per wave.
@@ -369,7 +372,7 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<
                     else if (h1) { node = c1; pop = false; }
                 } else {
                     uint32_t code = uint32_t(~node);
-                    uint32_t first = code >> 3, count = (code & 7u) + 1u;
+                    uint32_t first = code >> 4, count = (code & 15u) + 1u;  // slots; holes are degenerate records (det = 0: culled)
                     for (uint32_t i = 0; i < count; i++) {
                         const TriRec<R>& tr = tris[first + i];
                         if (STATS) cnt.tri_tests++;
@@ -422,6 +425,91 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<
 // Closest-hit semantics are those of the in-order program: the nearest t wins and, at exactly equal
 // t, the op that comes first in the reference's visiting order (its tests use strict `t < closest`).
 // ---------------------------------------------------------------------------------------------
+// The scene program over everything except the (single) deferred mesh op: closest hit of `wray` with the spheres /
+// quads / sky / sun in `best`; returns true if the ray also has to visit the mesh (its object-space ray enters the
+// mesh's box inside the interval the other primitives left).  Uniform control flow over the wave: every lane
+// walks the same program.
+template <typename R, bool STATS>
+RT_DEV bool prims_search(const SceneView<R>& sc, const Ray<R>& wray, int32_t mesh_pc, Best<R>& best, LaneCounters& cnt) {
+    const R t_lo = R(0.001);
+    Ray<R> cur = wray;
+    Ray<R> mesh_ray = wray;
+    best.t = Lim<R>::inf(); best.pc = -1; best.tri = -1; best.u = R(0); best.v = R(0);
+    bool mesh_reached = false;
+    int32_t pc = 0;
+    if (STATS) cnt.rays++;
+    for (;;) {
+        const Op op = sc.ops[pc];
+        if (op.type == OP_END) break;
+        switch (op.type) {
+            case OP_BOUNDS:
+                if (!test_bounding_box(sc.bounds[op.arg], cur, t_lo, best.t)) {
+                    pc = op.skip;
+                    continue;
+                }
+                break;
+            case OP_XFORM_PUSH: {
+                const Xform<R>& x = sc.xforms[op.arg];
+                cur = make_ray(xform_apply(x.inv, cur.o, R(1)), xform_apply(x.inv, cur.d, R(0)));
+                break;
+            }
+            case OP_XFORM_POP:
+                cur = ray_in_chain(sc, wray, op.chain);
+                break;
+            case OP_SPHERE: {
+                R t;
+                if (STATS) cnt.prim_tests++;
+                if (sphere_test(sc.spheres[op.arg], cur, t_lo, best.t, t)) { best.t = t; best.pc = pc; }
+                break;
+            }
+            case OP_PLANE: {
+                R t, u, v;
+                if (STATS) cnt.prim_tests++;
+                if (plane_test(sc.planes[op.arg], cur, t_lo, best.t, t, u, v)) { best.t = t; best.pc = pc; best.u = u; best.v = v; }
+                break;
+            }
+            case OP_MESH:  // deferred (pc == mesh_pc: the only mesh op of this program)
+                mesh_reached = true;
+                mesh_ray = cur;
+                break;
+            case OP_SKY:
+                if (STATS) cnt.prim_tests++;
+                if (!(Lim<R>::inf() > best.t)) { best.t = Lim<R>::inf(); best.pc = pc; }
+                break;
+            case OP_SUN: {
+                if (STATS) cnt.prim_tests++;
+                const SunPrim<R>& s = sc.suns[op.arg];
+                V3<R> unit_dir = to_unit(cur.d);
+                if (!(fabs(dot(ld3(s.direction), unit_dir) - R(1)) > R(0.001)) && !(Lim<R>::max() >= best.t)) {
+                    best.t = Lim<R>::max();
+                    best.pc = pc;
+                }
+                break;
+            }
+            default: break;
+        }
+        pc++;
+    }
+    if (!mesh_reached) return false;
+    // does the ray enter the mesh's box inside (t_lo, best.t]?  (culling only: conservative)
+    const Bounds<R>& rb = sc.mesh_bounds[sc.ops[mesh_pc].arg];
+    const R big = sizeof(R) == 8 ? R(1e150) : R(1e18);
+    V3<R> inv = {fabs(mesh_ray.inv.x) > big ? copysign(big, mesh_ray.inv.x) : mesh_ray.inv.x,
+                 fabs(mesh_ray.inv.y) > big ? copysign(big, mesh_ray.inv.y) : mesh_ray.inv.y,
+                 fabs(mesh_ray.inv.z) > big ? copysign(big, mesh_ray.inv.z) : mesh_ray.inv.z};
+    // a few ulps of slack on the box: this test must never be stricter than the traversal
+    const R eps = Lim<R>::eps() * R(16);
+    R t0x = (rb.lo[0] - fabs(rb.lo[0]) * eps - mesh_ray.o.x) * inv.x, t1x = (rb.hi[0] + fabs(rb.hi[0]) * eps - mesh_ray.o.x) * inv.x;
+    R t0y = (rb.lo[1] - fabs(rb.lo[1]) * eps - mesh_ray.o.y) * inv.y, t1y = (rb.hi[1] + fabs(rb.hi[1]) * eps - mesh_ray.o.y) * inv.y;
+    R t0z = (rb.lo[2] - fabs(rb.lo[2]) * eps - mesh_ray.o.z) * inv.z, t1z = (rb.hi[2] + fabs(rb.hi[2]) * eps - mesh_ray.o.z) * inv.z;
+    R tn = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmax(fmin(t0z, t1z), t_lo));
+    R tf = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmin(fmax(t0z, t1z), best.t));
+    tf = tf + fabs(tf) * eps;
+    return (tn <= tf) && rb.lo[0] <= rb.hi[0];
+}
+
+// Stand-alone form: only the FIRST iteration of a replica group needs it (the camera rays of k_wf_generate); from
+// then on k_wf_shade<FUSE> runs prims_search on every new ray while it is still in registers.
 template <typename R, bool STATS, bool LDS>
 __global__ void __launch_bounds__(256) k_wf_prims(SceneView<R> sc_g, WfPool<R> pool, const uint32_t* __restrict__ queue,
                                                   uint32_t* __restrict__ mesh_queue, WfCounters* __restrict__ ctr,
@@ -438,96 +526,20 @@ __global__ void __launch_bounds__(256) k_wf_prims(SceneView<R> sc_g, WfPool<R> p
     const bool full = n == pool.capacity;
     const uint32_t begin = blockIdx.x * WF_CHUNK;
     const uint32_t end = min(n, begin + WF_CHUNK);
-    const R t_lo = R(0.001);
     LaneCounters cnt;
     for (uint32_t base = begin; base < end; base += blockDim.x) {
-    const uint32_t i = base + threadIdx.x;
-    bool active = i < end;
-    bool to_mesh = false;
-    uint32_t slot = 0;
-    if (active) {
-        slot = full ? i : queue[i];
-        const Ray<R> wray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
-        Ray<R> cur = wray;
-        Ray<R> mesh_ray = wray;
-        Best<R> best;
-        best.t = Lim<R>::inf(); best.pc = -1; best.tri = -1; best.u = R(0); best.v = R(0);
-        bool mesh_reached = false;
-        int32_t pc = 0;
-        if (STATS) cnt.rays++;
-        for (;;) {
-            const Op op = sc.ops[pc];
-            if (op.type == OP_END) break;
-            switch (op.type) {
-                case OP_BOUNDS:
-                    if (!test_bounding_box(sc.bounds[op.arg], cur, t_lo, best.t)) {
-                        pc = op.skip;
-                        continue;
-                    }
-                    break;
-                case OP_XFORM_PUSH: {
-                    const Xform<R>& x = sc.xforms[op.arg];
-                    cur = make_ray(xform_apply(x.inv, cur.o, R(1)), xform_apply(x.inv, cur.d, R(0)));
-                    break;
-                }
-                case OP_XFORM_POP:
-                    cur = ray_in_chain(sc, wray, op.chain);
-                    break;
-                case OP_SPHERE: {
-                    R t;
-                    if (STATS) cnt.prim_tests++;
-                    if (sphere_test(sc.spheres[op.arg], cur, t_lo, best.t, t)) { best.t = t; best.pc = pc; }
-                    break;
-                }
-                case OP_PLANE: {
-                    R t, u, v;
-                    if (STATS) cnt.prim_tests++;
-                    if (plane_test(sc.planes[op.arg], cur, t_lo, best.t, t, u, v)) { best.t = t; best.pc = pc; best.u = u; best.v = v; }
-                    break;
-                }
-                case OP_MESH:  // deferred (pc == mesh_pc: the only mesh op of this program)
-                    mesh_reached = true;
-                    mesh_ray = cur;
-                    break;
-                case OP_SKY:
-                    if (STATS) cnt.prim_tests++;
-                    if (!(Lim<R>::inf() > best.t)) { best.t = Lim<R>::inf(); best.pc = pc; }
-                    break;
-                case OP_SUN: {
-                    if (STATS) cnt.prim_tests++;
-                    const SunPrim<R>& s = sc.suns[op.arg];
-                    V3<R> unit_dir = to_unit(cur.d);
-                    if (!(fabs(dot(ld3(s.direction), unit_dir) - R(1)) > R(0.001)) && !(Lim<R>::max() >= best.t)) {
-                        best.t = Lim<R>::max();
-                        best.pc = pc;
-                    }
-                    break;
-                }
-                default: break;
-            }
-            pc++;
+        const uint32_t i = base + threadIdx.x;
+        bool to_mesh = false;
+        uint32_t slot = 0;
+        if (i < end) {
+            slot = full ? i : queue[i];
+            const Ray<R> wray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
+            Best<R> best;
+            to_mesh = prims_search<R, STATS>(sc, wray, mesh_pc, best, cnt);
+            pool.ht[slot] = best.t; pool.hu[slot] = best.u; pool.hv[slot] = best.v;
+            pool.hpc[slot] = best.pc; pool.htri[slot] = best.tri;
         }
-        pool.ht[slot] = best.t; pool.hu[slot] = best.u; pool.hv[slot] = best.v;
-        pool.hpc[slot] = best.pc; pool.htri[slot] = best.tri;
-        if (mesh_reached) {
-            // does the ray enter the mesh's box inside (t_lo, best.t]?  (culling only: conservative)
-            const Bounds<R>& rb = sc.mesh_bounds[sc.ops[mesh_pc].arg];
-            const R big = sizeof(R) == 8 ? R(1e150) : R(1e18);
-            V3<R> inv = {fabs(mesh_ray.inv.x) > big ? copysign(big, mesh_ray.inv.x) : mesh_ray.inv.x,
-                         fabs(mesh_ray.inv.y) > big ? copysign(big, mesh_ray.inv.y) : mesh_ray.inv.y,
-                         fabs(mesh_ray.inv.z) > big ? copysign(big, mesh_ray.inv.z) : mesh_ray.inv.z};
-            // a few ulps of slack on the box: this test must never be stricter than the traversal
-            const R eps = Lim<R>::eps() * R(16);
-            R t0x = (rb.lo[0] - fabs(rb.lo[0]) * eps - mesh_ray.o.x) * inv.x, t1x = (rb.hi[0] + fabs(rb.hi[0]) * eps - mesh_ray.o.x) * inv.x;
-            R t0y = (rb.lo[1] - fabs(rb.lo[1]) * eps - mesh_ray.o.y) * inv.y, t1y = (rb.hi[1] + fabs(rb.hi[1]) * eps - mesh_ray.o.y) * inv.y;
-            R t0z = (rb.lo[2] - fabs(rb.lo[2]) * eps - mesh_ray.o.z) * inv.z, t1z = (rb.hi[2] + fabs(rb.hi[2]) * eps - mesh_ray.o.z) * inv.z;
-            R tn = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmax(fmin(t0z, t1z), t_lo));
-            R tf = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmin(fmax(t0z, t1z), best.t));
-            tf = tf + fabs(tf) * eps;
-            to_mesh = (tn <= tf) && rb.lo[0] <= rb.hi[0];
-        }
-    }
-    lds_append(to_mesh, slot, mesh_list, &lc[0]);
+        lds_append(to_mesh, slot, mesh_list, &lc[0]);
     }
     __syncthreads();
     const uint32_t n_list = lc[0];
@@ -599,12 +611,12 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
     const MeshInst mi = sc.meshes[mop.arg];
     const Bounds<R> rb = sc.mesh_bounds[mop.arg];
     const BvhNode4f* nodes = sc.nodes4 + mi.node4_base;
-    const TriRec<R>* tris = sc.tris + mi.tri_base;
+    const TriPair<R>* pairs = sc.pairs + mi.tri_base / 2u;
     const bool hit_back = (mi.flags & RT_MESH_HIT_BACK_FACES) != 0;
     const R big = sizeof(R) == 8 ? R(1e150) : R(1e18);
 
     LaneCounters cnt;
-    uint32_t w_node = 0, w_tri = 0, w_refill = 0, l_refill = 0, l_culled = 0;  // STATS: see DeviceCounters
+    uint32_t w_node = 0, w_tri = 0, w_refill = 0, l_refill = 0, l_culled = 0, l_recs = 0;  // STATS: see DeviceCounters
     bool has = false;
     bool exhausted = false;
     bool found = false;      // a triangle closer than the other primitives' hit was found
@@ -746,13 +758,18 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
         // ---- leaves: the (lane, triangle) pairs of all lanes that hold a leaf are FLATTENED over the wave, so
         //      that 64 triangle tests run per pass whatever the leaf sizes are (a per-lane loop ran at 33 % lane
         //      utilisation: leaves hold 1..4 triangles and a third of the lanes hold none).  Every pass: pair w ->
-        //      (owner lane, k) through a wave-private LDS table, the owner's ray through cross-lane reads, one exact
-        //      test in R, result into LDS; the owners then take their results in k order with the reference's
-        //      interval rule, which makes the outcome identical to the sequential loop (mesh.rs:62-107). ----
+        //      (owner lane, slot in leaf) through a wave-private LDS table, the owner's ray through cross-lane reads,
+        //      one exact test in R on the ten values of its half of a leaf RECORD (rt_scene.h, TriPair: one aligned
+        //      line holds a fan of two triangles), result into LDS; the owners then take their results with the
+        //      reference's interval rule (mesh.rs:62-107: strictly nearer wins, so among equal t the lowest slot
+        //      does — made explicit here, the results of one leaf arrive pair records first). ----
         {
             const bool leaf = has && node < 0;
             const uint32_t code = uint32_t(~node);
-            const uint32_t first = leaf ? (code >> 3) : 0u, count = leaf ? ((code & 7u) + 1u) : 0u;
+            const uint32_t first_rec = leaf ? (code >> kLeaf4RecShift) : 0u;
+            const uint32_t n_rec = ((code >> 3) & 7u) + 1u;
+            const uint32_t count = leaf ? ((code & 7u) + 1u) : 0u;   // triangles
+            const uint32_t n_two = count - (leaf ? n_rec : 0u);       // records that hold two: they come first
             uint32_t pre = 0, total = 0;
 #pragma unroll
             for (int bit = 0; bit < 4; bit++) {
@@ -761,32 +778,37 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
                 total += uint32_t(__popcll(m)) << bit;
             }
             if (total != 0u) {
+                // triangle j of the leaf -> slot within the leaf (2 x record + half)
+                auto slot_of = [&](uint32_t j) { return j < 2u * n_two ? j : 2u * (j - n_two); };
                 for (uint32_t j = 0; j < 8u; j++) {
                     if (__ballot(j < count) == 0ull) break;
-                    if (j < count) pair_tbl[pre + j] = uint16_t(lane | (j << 8));
+                    if (j < count) pair_tbl[pre + j] = uint16_t(lane | (slot_of(j) << 8));
                 }
                 __builtin_amdgcn_wave_barrier();
+                bool set_here = false;  // this lane's current hit was found in THIS leaf (ties go to the lower slot)
                 for (uint32_t c0 = 0; c0 < total; c0 += 64u) {
                     if (STATS) w_tri++;
                     const uint32_t w = c0 + lane;
                     const bool act = w < total;
                     const uint32_t e = act ? uint32_t(pair_tbl[w]) : 0u;
                     const int owner = int(e & 0xFFu);
-                    const uint32_t k = e >> 8;
+                    const uint32_t q = e >> 8;  // slot within the owner's leaf
                     const V3<R> po = {__shfl(o.x, owner), __shfl(o.y, owner), __shfl(o.z, owner)};
                     const V3<R> pd = {__shfl(d.x, owner), __shfl(d.y, owner), __shfl(d.z, owner)};
-                    const uint32_t pfirst = uint32_t(__shfl(int(first), owner));
-                    R rt = Lim<R>::inf(), ru = R(0), rv = R(0);  // t = +inf: "no hit" (fails `t_max <= t` at the owner)
+                    const uint32_t pfirst = uint32_t(__shfl(int(first_rec), owner));
+                    R rt = Lim<R>::inf(), ru = R(0), rv = R(0);  // t = +inf: "no hit" (fails `t < t_max` at the owner)
                     if (act) {
-                        const TriRec<R>& tr = tris[pfirst + k];
+                        using R2 = typename std::conditional<sizeof(R) == 8, double2, float2>::type;
+                        const R2* rec = reinterpret_cast<const R2*>(pairs[pfirst + (q >> 1)].q + 6u * (q & 1u));
+                        const R2 r01 = rec[0], r23 = rec[1], r45 = rec[2], r67 = rec[3], r89 = rec[4];
                         if (STATS) cnt.tri_tests++;
-                        V3<R> edge1 = ld3(tr.e1), edge2 = ld3(tr.e2);
+                        const V3<R> edge1 = {r01.x, r01.y, r23.x}, v0 = {r45.x, r45.y, r23.y}, edge2 = {r67.x, r67.y, r89.x};
                         V3<R> ray_x_edge2 = cross(pd, edge2);
                         R det = dot(edge1, ray_x_edge2);
                         R dd = hit_back ? fabs(det) : det;
                         if (!(dd < Lim<R>::eps())) {
                             R inv_det = R(1) / det;
-                            V3<R> b = po - ld3(tr.v0);
+                            V3<R> b = po - v0;
                             R u = dot(b, ray_x_edge2) * inv_det;
                             if (!(u < R(0) || u > R(1))) {
                                 V3<R> b_x_edge1 = cross(b, edge1);
@@ -807,15 +829,19 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
                         for (int j = jlo; j < jhi; j++) {
                             const int idx = int(pre) + j - int(c0);
                             const R t = res_t[idx];
-                            if (t <= t_lo || t_max <= t) continue;
+                            if (t <= t_lo) continue;
+                            const int32_t slot_abs = int32_t(mi.tri_base + 2u * first_rec + slot_of(uint32_t(j)));
+                            if (t_max <= t && !(set_here && t == t_max && slot_abs < hit_tri)) continue;
                             t_max = t; hit_u = res_u[idx]; hit_v = res_v[idx];
-                            hit_tri = int32_t(mi.tri_base + first + uint32_t(j));
+                            hit_tri = slot_abs;
                             found = true;
+                            set_here = true;
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
                 if (leaf) {
+                    if (STATS) l_recs += n_rec;
                     tmax32 = f32_at_least(t_max - t_shift);
                     pop_next();
                 }
@@ -828,6 +854,7 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
         atomicAdd(&counters->tri_tests, (unsigned long long)cnt.tri_tests);
         atomicAdd(&counters->refill_lanes, (unsigned long long)l_refill);
         atomicAdd(&counters->pops_culled, (unsigned long long)l_culled);
+        atomicAdd(&counters->leaf_records, (unsigned long long)l_recs);
         uint32_t wn = w_node, wt = w_tri, wr = w_refill;  // wave-uniform
         if ((threadIdx.x & 63u) == 0) {
             atomicAdd(&counters->node_wave_iters, (unsigned long long)wn);
@@ -845,14 +872,20 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
 #else
 #define RT_SHADE_BOUNDS __launch_bounds__(256)
 #endif
-template <typename R, bool STATS, bool LDS, bool TEX>
+// FUSE: the scene has the split intersect (one mesh op, or none): the primitive program (prims_search) runs HERE on
+// every new ray — scattered or regenerated — while it is still in registers, writes the closest primitive hit and
+// queues the ray for k_wf_mesh.  Without it a separate k_wf_prims pass re-read every ray from the pool each iteration
+// (48 B in, 40 B out per ray, one more launch per iteration: 12 % of the headline step in round 1).
+template <typename R, bool STATS, bool LDS, bool TEX, bool FUSE>
 __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam, ParamsView<R> prm, WfPool<R> pool, WfGroup<R> grp,
-                                                  const uint32_t* __restrict__ queue_in, uint32_t* __restrict__ queue_out,
-                                                  WfCounters* __restrict__ ctr, double* __restrict__ sample_L, DeviceCounters* counters) {
+                                           const uint32_t* __restrict__ queue_in, uint32_t* __restrict__ queue_out,
+                                           WfCounters* __restrict__ ctr, double* __restrict__ sample_L, DeviceCounters* counters,
+                                           uint32_t* __restrict__ mesh_queue, int32_t mesh_pc) {
     extern __shared__ __align__(16) char lds_raw[];
     uint32_t* alive_list = reinterpret_cast<uint32_t*>(lds_raw);  // [WF_CHUNK] slots that go to the next queue
     uint32_t* dead_list = alive_list + WF_CHUNK;                 // [WF_CHUNK] slots whose path ended
-    uint32_t* lc = dead_list + WF_CHUNK;                         // [0] n_alive [1] n_dead [2,3] sample base [4] queue base
+    uint32_t* mesh_list = dead_list + WF_CHUNK;                  // [WF_CHUNK] (FUSE) slots whose new ray must visit the mesh
+    uint32_t* lc = mesh_list + (FUSE ? WF_CHUNK : 0u);           // [0] n_alive [1] n_dead [2,3] sample base [4] queue base [5] n_mesh [6] mesh queue base
     char* tables = reinterpret_cast<char*>(lc + 8);
     if (threadIdx.x < 8) lc[threadIdx.x] = 0;
     SceneView<R> sc = sc_g;
@@ -868,52 +901,60 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
     LaneCounters cnt;
     // ---- phase 1: one path vertex per lane, chunk by chunk ----
     for (uint32_t base = begin; base < end; base += blockDim.x) {
-    const uint32_t i = base + threadIdx.x;
-    bool active = i < end;
-    bool alive = false;
-    uint32_t slot = 0;
-    if (active) {
-        slot = full ? i : queue_in[i];
-        PathState<R> ps;
-        ps.ray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
-        Best<R> best;
-        best.t = pool.ht[slot]; best.u = pool.hu[slot]; best.v = pool.hv[slot];
-        best.pc = pool.hpc[slot]; best.tri = pool.htri[slot];
-        // Resolve the hit BEFORE the rest of the path state is loaded: the compiler otherwise hoists those loads
-        // above resolve_hit's loops (texture walk, transform chain) and keeps 16 more values live across them.
-        HitInfo<R> hit{};
-        if (best.pc >= 0) hit = resolve_hit<R, TEX>(sc, ps.ray, best);
-        asm volatile("" ::: "memory");
-        ps.throughput = mk<R>(pool.tr[slot], pool.tg[slot], pool.tb[slot]);
-        ps.radiance = mk<R>(0, 0, 0);
-        ps.depth = pool.depth[slot];
-        Rng rng;
-        rng.s = pool.rng[slot];
-        bool cont;
-        if (best.pc < 0) {  // camera.rs:331 background
-            ps.radiance = ps.throughput * ld3(prm.background);
-            cont = false;
-        } else {
-            cont = shade_hit<R, STATS, TEX>(sc, prm, ps, hit, rng, cnt);
+        const uint32_t i = base + threadIdx.x;
+        const bool active = i < end;
+        bool alive = false;
+        bool to_mesh = false;
+        uint32_t slot = 0;
+        if (active) {
+            slot = full ? i : queue_in[i];
+            PathState<R> ps;
+            ps.ray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
+            Best<R> best;
+            best.t = pool.ht[slot]; best.u = pool.hu[slot]; best.v = pool.hv[slot];
+            best.pc = pool.hpc[slot]; best.tri = pool.htri[slot];
+            // Resolve the hit BEFORE the rest of the path state is loaded: the compiler otherwise hoists those loads
+            // above resolve_hit's loops (texture walk, transform chain) and keeps more values live across them.
+            HitInfo<R> hit{};
+            if (best.pc >= 0) hit = resolve_hit<R, TEX>(sc, ps.ray, best);
+            asm volatile("" ::: "memory");
+            ps.throughput = mk<R>(pool.tr[slot], pool.tg[slot], pool.tb[slot]);
+            ps.radiance = mk<R>(0, 0, 0);
+            ps.depth = pool.depth[slot];
+            Rng rng;
+            rng.s = pool.rng[slot];
+            bool cont;
+            if (best.pc < 0) {  // camera.rs:331 background
+                ps.radiance = ps.throughput * ld3(prm.background);
+                cont = false;
+            } else {
+                cont = shade_hit<R, STATS, TEX>(sc, prm, ps, hit, rng, cnt);
+            }
+            ps.depth--;
+            if (cont && ps.depth != 0) {  // depth == 0: ray_color returns black without tracing (camera.rs:290)
+                pool.ox[slot] = ps.ray.o.x; pool.oy[slot] = ps.ray.o.y; pool.oz[slot] = ps.ray.o.z;
+                pool.dx[slot] = ps.ray.d.x; pool.dy[slot] = ps.ray.d.y; pool.dz[slot] = ps.ray.d.z;
+                pool.tr[slot] = ps.throughput.x; pool.tg[slot] = ps.throughput.y; pool.tb[slot] = ps.throughput.z;
+                pool.rng[slot] = rng.s;
+                pool.depth[slot] = ps.depth;
+                alive = true;
+                if constexpr (FUSE) {
+                    Best<R> nb;
+                    to_mesh = prims_search<R, STATS>(sc, ps.ray, mesh_pc, nb, cnt);
+                    pool.ht[slot] = nb.t; pool.hu[slot] = nb.u; pool.hv[slot] = nb.v;
+                    pool.hpc[slot] = nb.pc; pool.htri[slot] = nb.tri;
+                }
+            } else {
+                if (cont) end_black(ps);  // depth exhausted: the next ray_color call returns black (camera.rs:290)
+                uint64_t s = pool.sample[slot];
+                sample_L[3 * s + 0] = double(ps.radiance.x);
+                sample_L[3 * s + 1] = double(ps.radiance.y);
+                sample_L[3 * s + 2] = double(ps.radiance.z);
+            }
         }
-        ps.depth--;
-        if (cont && ps.depth != 0) {  // depth == 0: ray_color returns black without tracing (camera.rs:290)
-            pool.ox[slot] = ps.ray.o.x; pool.oy[slot] = ps.ray.o.y; pool.oz[slot] = ps.ray.o.z;
-            pool.dx[slot] = ps.ray.d.x; pool.dy[slot] = ps.ray.d.y; pool.dz[slot] = ps.ray.d.z;
-            pool.tr[slot] = ps.throughput.x; pool.tg[slot] = ps.throughput.y; pool.tb[slot] = ps.throughput.z;
-            pool.rng[slot] = rng.s;
-            pool.depth[slot] = ps.depth;
-            alive = true;
-        } else {
-            if (cont) end_black(ps);  // depth exhausted: the next ray_color call returns black (camera.rs:290)
-            uint64_t s = pool.sample[slot];
-            sample_L[3 * s + 0] = double(ps.radiance.x);
-            sample_L[3 * s + 1] = double(ps.radiance.y);
-            sample_L[3 * s + 2] = double(ps.radiance.z);
-        }
-    }
-    lds_append(active && alive, slot, alive_list, &lc[0]);
-    lds_append(active && !alive, slot, dead_list, &lc[1]);
+        lds_append(active && alive, slot, alive_list, &lc[0]);
+        lds_append(active && !alive, slot, dead_list, &lc[1]);
+        if constexpr (FUSE) lds_append(to_mesh, slot, mesh_list, &lc[5]);
     }
     __syncthreads();
     // ---- phase 2: finished paths restart IN PLACE on the next samples (one global atomic per workgroup;
@@ -929,28 +970,46 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
     for (uint32_t j0 = 0; j0 < n_dead; j0 += blockDim.x) {
         const uint32_t j = j0 + threadIdx.x;
         bool restarted = false;
+        bool to_mesh = false;
         uint32_t slot = 0;
         if (j < n_dead) {
             const unsigned long long s2 = s_base + j;
             slot = dead_list[j];
             if (s2 < grp.total) {
-                wf_start_sample(pool, slot, s2, grp, cam, prm);
+                const Ray<R> ray = wf_start_sample(pool, slot, s2, grp, cam, prm);
                 restarted = true;
+                if constexpr (FUSE) {
+                    Best<R> nb;
+                    to_mesh = prims_search<R, STATS>(sc, ray, mesh_pc, nb, cnt);
+                    pool.ht[slot] = nb.t; pool.hu[slot] = nb.u; pool.hv[slot] = nb.v;
+                    pool.hpc[slot] = nb.pc; pool.htri[slot] = nb.tri;
+                }
             }
         }
         lds_append(restarted, slot, alive_list, &lc[0]);
+        if constexpr (FUSE) lds_append(to_mesh, slot, mesh_list, &lc[5]);
     }
     __syncthreads();
-    // ---- phase 3: surviving slots -> next queue (one global atomic per workgroup, coalesced copy) ----
+    // ---- phase 3: surviving slots -> next queue, mesh list -> next mesh queue (one global atomic per workgroup and
+    //      list, coalesced copies) ----
     const uint32_t n_alive = lc[0];
+    const uint32_t n_list = FUSE ? lc[5] : 0u;
     if (threadIdx.x == 0 && n_alive) lc[4] = atomicAdd(&ctr->n_out, n_alive);
+    if (FUSE && threadIdx.x == 64 && n_list) lc[6] = atomicAdd(&ctr->n_mesh_next, n_list);
     __syncthreads();
     const uint32_t qb = lc[4];
     for (uint32_t j = threadIdx.x; j < n_alive; j += blockDim.x) queue_out[qb + j] = alive_list[j];
+    if constexpr (FUSE) {
+        const uint32_t mb = lc[6];
+        for (uint32_t j = threadIdx.x; j < n_list; j += blockDim.x) mesh_queue[mb + j] = mesh_list[j];
+    }
     if (STATS) {
-        uint32_t prims = cnt.prim_tests;
-        for (int off = 32; off > 0; off >>= 1) prims += __shfl_down(prims, off);
-        if ((threadIdx.x & 63u) == 0 && prims) atomicAdd(&counters->prim_tests, (unsigned long long)prims);
+        uint32_t rays = cnt.rays, prims = cnt.prim_tests;
+        for (int off = 32; off > 0; off >>= 1) { rays += __shfl_down(rays, off); prims += __shfl_down(prims, off); }
+        if ((threadIdx.x & 63u) == 0 && (prims | rays)) {
+            atomicAdd(&counters->prim_tests, (unsigned long long)prims);
+            if (rays) atomicAdd(&counters->rays, (unsigned long long)rays);
+        }
     }
 }
 
@@ -959,7 +1018,8 @@ __global__ void k_wf_advance(WfCounters* ctr) {
     ctr->n_in = ctr->n_out;
     ctr->n_out = 0;
     ctr->cursor = 0;
-    ctr->n_mesh = 0;
+    ctr->n_mesh = ctr->n_mesh_next;  // filled by k_wf_shade<FUSE> (0 otherwise)
+    ctr->n_mesh_next = 0;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -208,13 +208,14 @@ def test_every_kernel_variant_is_bit_identical(dev, name, monkeypatch):
     p.pipeline = api.RT_PIPELINE_WAVEFRONT
     for stats in (0, 1):
         for lds in ("1", "0"):
-            for split in ("1", "0"):
+            for split, fuse in (("1", "0"), ("1", "1"), ("0", "0")):
                 monkeypatch.setenv("RT_LDS_TABLES", lds)
                 monkeypatch.setenv("RT_WF_SPLIT", split)
+                monkeypatch.setenv("RT_WF_FUSE", fuse)    # primitive program inside k_wf_shade instead of a separate pass
                 p.collect_stats = stats
                 wf = scene.render(hs.camera, p)
                 same = (wf == mega) | (np.isnan(wf) & np.isnan(mega))
-                assert same.all(), f"variant stats={stats} lds={lds} split={split}: {int((~same).any(axis=2).sum())} pixels differ"
+                assert same.all(), f"variant stats={stats} lds={lds} split={split} fuse={fuse}: {int((~same).any(axis=2).sum())} pixels differ"
 
 
 def test_stats_counters_and_collect_flag(dev):
@@ -226,7 +227,7 @@ def test_stats_counters_and_collect_flag(dev):
     st = scene.stats()
     assert st.samples == hs.width * hs.height * hs.spp
     assert st.rays >= st.samples and st.mesh_rays > 0 and st.node_visits > st.mesh_rays and st.tri_tests > 0
-    assert st.kernel_ms > 0 and st.bytes_node == 128 and st.bytes_tri == 80
+    assert st.kernel_ms > 0 and st.bytes_node == 128 and st.bytes_tri == 128 and 0 < st.leaf_records < st.tri_tests   # pair records: fewer line fetches than triangle tests
     assert st.pipeline_used == api.RT_PIPELINE_WAVEFRONT     # AUTO picks the wavefront scheduler for mesh scenes
     q = p.copy()
     q.pipeline = api.RT_PIPELINE_MEGAKERNEL
