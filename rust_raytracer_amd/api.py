@@ -213,8 +213,9 @@ def load_device_lib() -> C.CDLL:
         lib.rt_debug_trace_sample.restype = C.c_int
         lib.rt_scene_info.argtypes = [C.POINTER(RtSceneDesc), C.POINTER(C.c_uint32)]
         lib.rt_scene_info.restype = C.c_int
-        lib.rt_scene_mesh_stats.argtypes = [C.POINTER(RtSceneDesc), C.POINTER(C.c_uint64)]
-        lib.rt_scene_mesh_stats.restype = C.c_int
+        if hasattr(lib, "rt_scene_mesh_stats"):  # absent from older A/B builds loaded through RT_DEVICE_LIB
+            lib.rt_scene_mesh_stats.argtypes = [C.POINTER(RtSceneDesc), C.POINTER(C.c_uint64)]
+            lib.rt_scene_mesh_stats.restype = C.c_int
         lib.rt_last_error.argtypes = []
         lib.rt_last_error.restype = C.c_char_p
         _device_lib = lib

@@ -428,6 +428,7 @@ struct RtScene {
         size_t real_size = 0;          // sizeof(R) the pool was allocated for
         std::vector<void*> allocs;
         void* pool_view = nullptr;     // host copy of WfPool<R>
+        void* pool_dev = nullptr;      // the same descriptor in device memory (k_wf_shade re-reads the array bases from it)
         uint32_t* queue[2] = {nullptr, nullptr};
         uint32_t* mesh_queue = nullptr;
         void* mesh_spill = nullptr;        // k_wf_mesh: stack levels beyond the LDS part
@@ -540,6 +541,8 @@ static void wf_release_pool(RtScene::Wavefront& w) {
     w.allocs.clear();
     ::operator delete(w.pool_view);
     w.pool_view = nullptr;
+    if (w.pool_dev) (void)hipFree(w.pool_dev);
+    w.pool_dev = nullptr;
     for (int q = 0; q < 2; q++) {
         if (w.queue[q]) (void)hipFree(w.queue[q]);
         w.queue[q] = nullptr;
@@ -573,6 +576,8 @@ int wf_ensure(RtScene* s, uint32_t capacity) {
         if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->htri))) return st;
         for (int q = 0; q < 2; q++) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.queue[q]), size_t(capacity) * 4));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.mesh_queue), size_t(capacity) * 4));
+        HIP_TRY(hipMalloc(&w.pool_dev, sizeof(WfPool<R>)));
+        HIP_TRY(hipMemcpy(w.pool_dev, pool, sizeof(WfPool<R>), hipMemcpyHostToDevice));
         if (!w.d_ctr) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.d_ctr), sizeof(WfCounters)));
         if (!w.h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w.h_ctr), sizeof(WfCounters)));
         if (w.events.empty()) {
@@ -602,6 +607,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     const uint64_t per_replica = uint64_t(strata) * npix;
     // pool size: enough paths to keep every CU busy for several rounds per launch
     uint32_t capacity = env_u32("RT_WF_POOL", 1u << 25);  // 32M paths (5.5 GB of f64 state); measured at full size: 2M 322, 8M 377, 16M 393, 32M 404 Msamples/s
+    if (capacity > (1u << 28)) capacity = 1u << 28;  // the kernels address pool arrays through 32-bit byte offsets (rt_wavefront.h, at())
     if (uint64_t(capacity) > per_replica * T) capacity = uint32_t(per_replica * T);
     if (capacity < 64) capacity = 64;
     if (int st = wf_ensure<R>(s, capacity)) return st;
@@ -746,7 +752,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
 #undef RT_LAUNCH_ISECT
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 }
-#define RT_LAUNCH_SHADE(ST, L, TX, FU) hipLaunchKernelGGL((k_wf_shade<R, ST, L, TX, FU>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), (L ? lds_small : size_t(0)) + ((FU ? 3 : 2) * WF_CHUNK + 8) * 4 + shade_lds_pad, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters, w.mesh_queue, mesh_pc)
+#define RT_LAUNCH_SHADE(ST, L, TX, FU) hipLaunchKernelGGL((k_wf_shade<R, ST, L, TX, FU>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), (L ? lds_small : size_t(0)) + ((FU ? 3 : 2) * WF_CHUNK + 8) * 4 + shade_lds_pad, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters, w.mesh_queue, mesh_pc, static_cast<const WfPool<R>*>(w.pool_dev))
 #define RT_LAUNCH_SHADE_F(ST, L, TX) do { if (fuse) RT_LAUNCH_SHADE(ST, L, TX, true); else RT_LAUNCH_SHADE(ST, L, TX, false); } while (0)
                 if (tex) {  // interpreter variant: tables from global memory (rare scenes, fewer instantiations)
                     if (stats) RT_LAUNCH_SHADE_F(true, false, true); else RT_LAUNCH_SHADE_F(false, false, true);

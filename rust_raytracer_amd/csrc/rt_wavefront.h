@@ -28,13 +28,6 @@
 #ifndef RT_MESH_WAVES
 #define RT_MESH_WAVES 4
 #endif
-// NOTE: k_wf_shade deliberately has NO waves-per-SIMD hint: with `__launch_bounds__(256, 3)` and
-// `(256, 4)` hipcc (ROCm 7.2) produces wrong results (first Dielectric paths, later also the sphere-field scene;
-// caught by the bit-exact parity tests) and spills (80-320 B/lane): 4-5 % slower.  Re-measured after the shade
-// split below: same outcome.  At 197 VGPRs the f64 kernel runs 2 waves/SIMD; halving that costs +41 % of its
-// time (RT_WF_SHADE_LDS_PAD experiment), so a register diet would pay — the texture walk's loops are what
-// keeps ~55 VGPRs live (without them the kernel needs 144).
-
 namespace rt {
 
 template <typename R>
@@ -48,6 +41,14 @@ struct WfPool {
     R *ht, *hu, *hv;                 // closest hit: t, (u, v)
     int32_t *hpc, *htri;             // op that produced it (-1 none), triangle slot
 };
+
+// Element `slot` of a pool array through a 32-bit BYTE offset.  `base + zext(offset)` lets the compiler address every
+// array of one element size with ONE offset VGPR and keep the array bases in SGPRs (global_load ... v_off, s[base:base+1]);
+// with 64-bit index arithmetic it kept a VGPR pair per array alive from the loads to the stores (22 VGPRs in k_wf_shade).
+// Pool sizes are capped at 2^28 slots by the driver, so the offset cannot wrap.
+template <typename T> RT_DEV T& at(T* base, uint32_t slot) {
+    return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + slot * uint32_t(sizeof(T)));
+}
 
 struct WfCounters {
     uint32_t n_in;        // entries of the current queue
@@ -86,12 +87,12 @@ RT_DEV Ray<R> wf_start_sample(const WfPool<R>& pool, uint32_t slot, uint64_t s, 
     Rng rng;
     rng.key(prm.seed, grp.tid0 + tid_local, uint64_t(py) * cam.width + px, st);
     Ray<R> ray = get_ray(cam, px, py, sx, sy, rng);
-    pool.ox[slot] = ray.o.x; pool.oy[slot] = ray.o.y; pool.oz[slot] = ray.o.z;
-    pool.dx[slot] = ray.d.x; pool.dy[slot] = ray.d.y; pool.dz[slot] = ray.d.z;
-    pool.tr[slot] = R(1); pool.tg[slot] = R(1); pool.tb[slot] = R(1);
-    pool.rng[slot] = rng.s;
-    pool.sample[slot] = s;
-    pool.depth[slot] = cam.max_depth;
+    at(pool.ox, slot) = ray.o.x; at(pool.oy, slot) = ray.o.y; at(pool.oz, slot) = ray.o.z;
+    at(pool.dx, slot) = ray.d.x; at(pool.dy, slot) = ray.d.y; at(pool.dz, slot) = ray.d.z;
+    at(pool.tr, slot) = R(1); at(pool.tg, slot) = R(1); at(pool.tb, slot) = R(1);
+    at(pool.rng, slot) = rng.s;
+    at(pool.sample, slot) = s;
+    at(pool.depth, slot) = cam.max_depth;
     return ray;
 }
 
@@ -204,13 +205,13 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<
             uint32_t my = 0;
             if (wave_fetch(range, idle, &ctr->cursor, n, exhausted, my)) {
                 slot = n == pool.capacity ? my : queue[my];  // full pool: identity order (see k_wf_shade)
-                wray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
+                wray = make_ray(mk<R>(at(pool.ox, slot), at(pool.oy, slot), at(pool.oz, slot)), mk<R>(at(pool.dx, slot), at(pool.dy, slot), at(pool.dz, slot)));
                 cur = wray;
                 best.t = Lim<R>::inf(); best.pc = -1; best.tri = -1; best.u = R(0); best.v = R(0);
                 pc = 0;
                 has = true;
                 in_mesh = false;
-                if constexpr (VOL) { rng.s = pool.rng[slot]; t_lo = t_lo_outer; }
+                if constexpr (VOL) { rng.s = at(pool.rng, slot); t_lo = t_lo_outer; }
                 if (STATS) cnt.rays++;
             }
         }
@@ -223,9 +224,9 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<
             for (;;) {
                 const Op op = sc.ops[pc];
                 if (op.type == OP_END) {
-                    pool.ht[slot] = best.t; pool.hu[slot] = best.u; pool.hv[slot] = best.v;
-                    pool.hpc[slot] = best.pc; pool.htri[slot] = best.tri;
-                    if constexpr (VOL) pool.rng[slot] = rng.s;
+                    at(pool.ht, slot) = best.t; at(pool.hu, slot) = best.u; at(pool.hv, slot) = best.v;
+                    at(pool.hpc, slot) = best.pc; at(pool.htri, slot) = best.tri;
+                    if constexpr (VOL) at(pool.rng, slot) = rng.s;
                     has = false;
                     break;
                 }
@@ -533,11 +534,11 @@ __global__ void __launch_bounds__(256) k_wf_prims(SceneView<R> sc_g, WfPool<R> p
         uint32_t slot = 0;
         if (i < end) {
             slot = full ? i : queue[i];
-            const Ray<R> wray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
+            const Ray<R> wray = make_ray(mk<R>(at(pool.ox, slot), at(pool.oy, slot), at(pool.oz, slot)), mk<R>(at(pool.dx, slot), at(pool.dy, slot), at(pool.dz, slot)));
             Best<R> best;
             to_mesh = prims_search<R, STATS>(sc, wray, mesh_pc, best, cnt);
-            pool.ht[slot] = best.t; pool.hu[slot] = best.u; pool.hv[slot] = best.v;
-            pool.hpc[slot] = best.pc; pool.htri[slot] = best.tri;
+            at(pool.ht, slot) = best.t; at(pool.hu, slot) = best.u; at(pool.hv, slot) = best.v;
+            at(pool.hpc, slot) = best.pc; at(pool.htri, slot) = best.tri;
         }
         lds_append(to_mesh, slot, mesh_list, &lc[0]);
     }
@@ -638,8 +639,8 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
             if (sp == 0) {
                 has = false;
                 if (found) {
-                    pool.ht[slot] = t_max; pool.hu[slot] = hit_u; pool.hv[slot] = hit_v;
-                    pool.hpc[slot] = mesh_pc; pool.htri[slot] = hit_tri;
+                    at(pool.ht, slot) = t_max; at(pool.hu, slot) = hit_u; at(pool.hv, slot) = hit_v;
+                    at(pool.hpc, slot) = mesh_pc; at(pool.htri, slot) = hit_tri;
                 }
                 return;
             }
@@ -663,7 +664,7 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
             if (wave_fetch(range, idle, &ctr->cursor, n, exhausted, my)) {
                 if (STATS) l_refill++;
                 slot = mesh_queue[my];
-                Ray<R> wray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
+                Ray<R> wray = make_ray(mk<R>(at(pool.ox, slot), at(pool.oy, slot), at(pool.oz, slot)), mk<R>(at(pool.dx, slot), at(pool.dy, slot), at(pool.dz, slot)));
                 Ray<R> ray = ray_in_chain(sc, wray, mop.chain);
                 o = ray.o;
                 d = ray.d;
@@ -691,8 +692,8 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
                 nearz = ivz < 0.0f ? 5u : 2u;
                 // The other primitives' closest hit bounds the search.  At exactly equal t the op that
                 // comes first in program order wins: if that is the mesh, t == bound must be accepted.
-                R bound = pool.ht[slot];
-                int32_t bpc = pool.hpc[slot];
+                R bound = at(pool.ht, slot);
+                int32_t bpc = at(pool.hpc, slot);
                 t_max = (bpc > mesh_pc && bound < Lim<R>::inf()) ? nextafter(bound, Lim<R>::inf()) : bound;
                 tmax32 = f32_at_least(t_max - t_shift);
                 found = false;
@@ -867,11 +868,14 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
 // ---------------------------------------------------------------------------------------------
 // Shade: one path vertex per lane (camera.rs:295-331), regeneration and queue compaction.
 // ---------------------------------------------------------------------------------------------
-#ifdef RT_SHADE_WAVES
-#define RT_SHADE_BOUNDS __launch_bounds__(256, RT_SHADE_WAVES)
-#else
-#define RT_SHADE_BOUNDS __launch_bounds__(256)
+// Waves per SIMD asked of the register allocator for k_wf_shade: 3 (<= 168 VGPRs) for the lean variant, which fits
+// without scratch since the store addresses are re-read (see the write-back) — the kernel is latency-bound and ran at
+// 2 waves (188-197 VGPRs) before.  The texture-interpreter and the fused variants need 205-256 registers: no cap
+// (it would cost them 70-330 B of scratch per lane).
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 3
 #endif
+#define RT_SHADE_BOUNDS __launch_bounds__(256, (TEX || FUSE) ? 1 : RT_SHADE_WAVES)
 // FUSE: the scene has the split intersect (one mesh op, or none): the primitive program (prims_search) runs HERE on
 // every new ray — scattered or regenerated — while it is still in registers, writes the closest primitive hit and
 // queues the ray for k_wf_mesh.  Without it a separate k_wf_prims pass re-read every ray from the pool each iteration
@@ -880,7 +884,7 @@ template <typename R, bool STATS, bool LDS, bool TEX, bool FUSE>
 __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam, ParamsView<R> prm, WfPool<R> pool, WfGroup<R> grp,
                                            const uint32_t* __restrict__ queue_in, uint32_t* __restrict__ queue_out,
                                            WfCounters* __restrict__ ctr, double* __restrict__ sample_L, DeviceCounters* counters,
-                                           uint32_t* __restrict__ mesh_queue, int32_t mesh_pc) {
+                                           uint32_t* __restrict__ mesh_queue, int32_t mesh_pc, const WfPool<R>* __restrict__ pool_dev) {
     extern __shared__ __align__(16) char lds_raw[];
     uint32_t* alive_list = reinterpret_cast<uint32_t*>(lds_raw);  // [WF_CHUNK] slots that go to the next queue
     uint32_t* dead_list = alive_list + WF_CHUNK;                 // [WF_CHUNK] slots whose path ended
@@ -909,20 +913,20 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
         if (active) {
             slot = full ? i : queue_in[i];
             PathState<R> ps;
-            ps.ray = make_ray(mk<R>(pool.ox[slot], pool.oy[slot], pool.oz[slot]), mk<R>(pool.dx[slot], pool.dy[slot], pool.dz[slot]));
+            ps.ray = make_ray(mk<R>(at(pool.ox, slot), at(pool.oy, slot), at(pool.oz, slot)), mk<R>(at(pool.dx, slot), at(pool.dy, slot), at(pool.dz, slot)));
             Best<R> best;
-            best.t = pool.ht[slot]; best.u = pool.hu[slot]; best.v = pool.hv[slot];
-            best.pc = pool.hpc[slot]; best.tri = pool.htri[slot];
+            best.t = at(pool.ht, slot); best.u = at(pool.hu, slot); best.v = at(pool.hv, slot);
+            best.pc = at(pool.hpc, slot); best.tri = at(pool.htri, slot);
             // Resolve the hit BEFORE the rest of the path state is loaded: the compiler otherwise hoists those loads
             // above resolve_hit's loops (texture walk, transform chain) and keeps more values live across them.
             HitInfo<R> hit{};
             if (best.pc >= 0) hit = resolve_hit<R, TEX>(sc, ps.ray, best);
             asm volatile("" ::: "memory");
-            ps.throughput = mk<R>(pool.tr[slot], pool.tg[slot], pool.tb[slot]);
+            ps.throughput = mk<R>(at(pool.tr, slot), at(pool.tg, slot), at(pool.tb, slot));
             ps.radiance = mk<R>(0, 0, 0);
-            ps.depth = pool.depth[slot];
+            ps.depth = at(pool.depth, slot);
             Rng rng;
-            rng.s = pool.rng[slot];
+            rng.s = at(pool.rng, slot);
             bool cont;
             if (best.pc < 0) {  // camera.rs:331 background
                 ps.radiance = ps.throughput * ld3(prm.background);
@@ -932,21 +936,26 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
             }
             ps.depth--;
             if (cont && ps.depth != 0) {  // depth == 0: ray_color returns black without tracing (camera.rs:290)
-                pool.ox[slot] = ps.ray.o.x; pool.oy[slot] = ps.ray.o.y; pool.oz[slot] = ps.ray.o.z;
-                pool.dx[slot] = ps.ray.d.x; pool.dy[slot] = ps.ray.d.y; pool.dz[slot] = ps.ray.d.z;
-                pool.tr[slot] = ps.throughput.x; pool.tg[slot] = ps.throughput.y; pool.tb[slot] = ps.throughput.z;
-                pool.rng[slot] = rng.s;
-                pool.depth[slot] = ps.depth;
+                // The array bases are re-read HERE from a copy of the pool descriptor in global memory (scalar loads): with
+                // the kernel-argument copy the compiler kept the eleven load addresses alive as VGPR pairs across the
+                // whole shading code to reuse them for these stores (22 VGPRs of a kernel that is occupancy-bound).
+                asm volatile("" ::: "memory");
+                const WfPool<R>& pw = *pool_dev;
+                at(pw.ox, slot) = ps.ray.o.x; at(pw.oy, slot) = ps.ray.o.y; at(pw.oz, slot) = ps.ray.o.z;
+                at(pw.dx, slot) = ps.ray.d.x; at(pw.dy, slot) = ps.ray.d.y; at(pw.dz, slot) = ps.ray.d.z;
+                at(pw.tr, slot) = ps.throughput.x; at(pw.tg, slot) = ps.throughput.y; at(pw.tb, slot) = ps.throughput.z;
+                at(pw.rng, slot) = rng.s;
+                at(pw.depth, slot) = ps.depth;
                 alive = true;
                 if constexpr (FUSE) {
                     Best<R> nb;
                     to_mesh = prims_search<R, STATS>(sc, ps.ray, mesh_pc, nb, cnt);
-                    pool.ht[slot] = nb.t; pool.hu[slot] = nb.u; pool.hv[slot] = nb.v;
-                    pool.hpc[slot] = nb.pc; pool.htri[slot] = nb.tri;
+                    at(pool.ht, slot) = nb.t; at(pool.hu, slot) = nb.u; at(pool.hv, slot) = nb.v;
+                    at(pool.hpc, slot) = nb.pc; at(pool.htri, slot) = nb.tri;
                 }
             } else {
                 if (cont) end_black(ps);  // depth exhausted: the next ray_color call returns black (camera.rs:290)
-                uint64_t s = pool.sample[slot];
+                uint64_t s = at(pool.sample, slot);
                 sample_L[3 * s + 0] = double(ps.radiance.x);
                 sample_L[3 * s + 1] = double(ps.radiance.y);
                 sample_L[3 * s + 2] = double(ps.radiance.z);
@@ -981,8 +990,8 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
                 if constexpr (FUSE) {
                     Best<R> nb;
                     to_mesh = prims_search<R, STATS>(sc, ray, mesh_pc, nb, cnt);
-                    pool.ht[slot] = nb.t; pool.hu[slot] = nb.u; pool.hv[slot] = nb.v;
-                    pool.hpc[slot] = nb.pc; pool.htri[slot] = nb.tri;
+                    at(pool.ht, slot) = nb.t; at(pool.hu, slot) = nb.u; at(pool.hv, slot) = nb.v;
+                    at(pool.hpc, slot) = nb.pc; at(pool.htri, slot) = nb.tri;
                 }
             }
         }

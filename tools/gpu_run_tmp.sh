@@ -1,4 +1,2 @@
 #!/bin/bash
-bash tools/gpu_sweep.sh RT_BVH_PAIRS 0 1
-bash tools/gpu_sweep.sh RT_BVH_MAX_LEAF 2 6 8
-bash tools/gpu_sweep.sh RT_WF_INNER_MIN 8 24 32
+bash tools/gpu_sweep.sh RT_DEVICE_LIB $PWD/tools/variants_oldmesh.so $PWD/rust_raytracer_amd/librt_mi355.so $PWD/tools/variants_oldmesh.so $PWD/rust_raytracer_amd/librt_mi355.so
