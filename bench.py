@@ -38,6 +38,9 @@ WORKLOADS = {
     "c3": (["scenes/light_test", "-w=1200", "-s=1000", "-t=10"],
            "scenes/light_test 1200x800 @1000spp, Suzanne 15.7k tri"),
     "c2": (["scenes/cornell", "-w=800", "-s=256"], "scenes/cornell 800x800 @256spp, quads + glass sphere"),
+    # the reference's built-in default scene (main.rs without a scene file: 440-sphere field in its object-BVH, Suzanne,
+    # sun + sky) at the size of samples/sample0.png; BASELINE config C1 is this scene at 400x266 @64spp on the CPU
+    "c1": (["-w=1200", "-s=256", "-t=4"], "default scene (golden_monkey.rs) 1200x800 @256spp, 440 spheres in an object BVH + Suzanne 15.7k tri"),
 }
 
 
@@ -130,9 +133,7 @@ def make_roofline(api, counters, kstats, a, owned_pixels, ms_per_step):
     mean = lambda k: sum(x[k] for x in kstats) / n
     launches = mean("launches")
     mega = counters.pipeline_used == api.RT_PIPELINE_MEGAKERNEL
-    # leaf data: one record per triangle test, or (wavefront mesh kernel) one aligned line per leaf record of 1-2 triangles
-    leaf_fetches = counters.leaf_records if counters.leaf_records else counters.tri_tests
-    bvh_bytes = counters.node_visits * counters.bytes_node + leaf_fetches * counters.bytes_tri
+    bvh_bytes = counters.node_visits * counters.bytes_node + counters.tri_tests * counters.bytes_tri
     if mega:
         cands = {"k_megakernel": (mean("all"), bvh_bytes + counters.mesh_rays * counters.bytes_attr + owned_pixels * 32, 1.0)}
     else:
@@ -164,9 +165,12 @@ def make_roofline(api, counters, kstats, a, owned_pixels, ms_per_step):
     out = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": None if cache_resident else achieved / HBM_PEAK_GBS, "traffic": traffic,
+        # what the memory side really moved for this kernel (counter bytes of the profiled run / this run's kernel time)
+        "frac_traffic": None if traffic is None else traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "kernel": name,
         "note": ("algorithmic bytes / kernel time (HIP events).  " +
-                 ("The working set of this kernel is served by L2 / the 256 MB Infinity Cache: its algorithmic rate is above the HBM peak, so no HBM fraction is given.  "
+                 ("The algorithmic rate of this kernel is ABOVE the HBM peak because part of its bytes is served by L1 / L2 and the 256 MB Infinity Cache "
+                  "(87 MB of BVH nodes and triangle records): `frac` is therefore null and `frac_traffic` = measured fabric-side bytes / kernel time / peak is the fraction to read.  "
                   if cache_resident else "") +
                  "`traffic` = rocprofv3 counter bytes of the same kernel per launch (2 x FETCH_SIZE + WRITE_SIZE, fabric side, "
                  "calibration in profiles/r01/fetch_size_calibration.txt), from profiles/traffic.json when this workload was profiled."),
@@ -184,8 +188,7 @@ def make_roofline(api, counters, kstats, a, owned_pixels, ms_per_step):
     if name.startswith("k_wf_mesh") and counters.node_visits:
         # the memory system's own limit for this access pattern (dependent fetches of random 128-B lines):
         # tools/ubench/gather_lines on the same chip, profiles/r01/ubench_gather_lines.txt
-        out["line_requests_per_s"] = (counters.node_visits * -(-counters.bytes_node // 128) + leaf_fetches * counters.bytes_tri / 128.0) / n_launch / (avg_ms * 1e-3)
-        out["leaf_records_per_ray"] = counters.leaf_records / counters.rays
+        out["line_requests_per_s"] = (counters.node_visits * -(-counters.bytes_node // 128) + counters.tri_tests * counters.bytes_tri / 128.0) / n_launch / (avg_ms * 1e-3)
         out["random_line_ceiling_per_s"] = [59e9, 79e9]
     return out
 

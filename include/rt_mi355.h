@@ -217,7 +217,7 @@ typedef struct RtRenderStats {
     uint64_t tri_tests;           /* Moller-Trumbore tests                                               */
     uint64_t prim_tests;          /* sphere/quad/sky/sun tests incl. light-pdf re-intersections          */
     uint64_t bytes_node;          /* bytes per BVH node in the layout used                               */
-    uint64_t bytes_tri;           /* bytes per triangle record (per leaf record when leaf_records != 0)  */
+    uint64_t bytes_tri;           /* bytes per triangle record                                           */
     uint64_t bytes_attr;          /* bytes of shading attributes fetched per mesh hit                    */
     uint64_t bytes_state;         /* bytes of path state the traversal kernel moves per ray it handles (0: megakernel) */
     /* wavefront scheduler only (0 otherwise): HIP-event sums per kernel of the iteration loop, and the
@@ -228,8 +228,6 @@ typedef struct RtRenderStats {
     uint64_t bytes_state_shade;
     uint32_t n_iterations;        /* wavefront iterations (one bounce of every live path each)             */
     uint32_t n_replica_groups;    /* groups the replicas were rendered in (per-sample buffer budget)       */
-    uint64_t leaf_records;        /* k_wf_mesh: leaf records fetched (one aligned line of bytes_tri bytes each, holding one or
-                                     two triangles); 0 for the kernels that fetch one record per triangle test */
 } RtRenderStats;
 
 typedef struct RtScene RtScene;
@@ -279,7 +277,7 @@ int rt_debug_trace_sample(const RtScene* scene, const RtCameraDesc* camera, cons
 #define RT_SCENE_INFO_VOLUMES 4u
 int rt_scene_info(const RtSceneDesc* desc, uint32_t* flags_out);
 /* Same, plus mesh statistics of the compiled scene (distinct meshes, host-built BVH):
- * out[0] triangles, out[1] leaf records, out[2] of which hold two triangles, out[3] BVH2 nodes, out[4] 4-wide nodes. */
+ * out[0] triangle records, out[1] BVH2 nodes, out[2] 4-wide nodes, out[3] BVH2 depth, out[4] worst-case 4-wide traversal stack. */
 int rt_scene_mesh_stats(const RtSceneDesc* desc, uint64_t out[5]);
 
 /* Message for the last non-RT_OK status on this thread ("" if none). */

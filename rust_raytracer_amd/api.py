@@ -114,8 +114,7 @@ class RtRenderStats(C.Structure):
                 ("bytes_state", C.c_uint64),
                 ("prims_kernel_ms", C.c_double), ("shade_kernel_ms", C.c_double),
                 ("bytes_state_prims", C.c_uint64), ("bytes_state_shade", C.c_uint64),
-                ("n_iterations", C.c_uint32), ("n_replica_groups", C.c_uint32),
-                ("leaf_records", C.c_uint64)]
+                ("n_iterations", C.c_uint32), ("n_replica_groups", C.c_uint32)]
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -236,13 +235,13 @@ def scene_info(desc) -> int:
 
 
 def scene_mesh_stats(desc) -> dict:
-    """rt_scene_mesh_stats: triangles / leaf records / pair records / BVH node counts (host only)."""
+    """rt_scene_mesh_stats: triangle records / BVH node counts / depths (host only)."""
     lib = load_device_lib()
     out = (C.c_uint64 * 5)()
     st = lib.rt_scene_mesh_stats(desc, out)
     if st != RT_OK:
         raise RtError(st, lib.rt_last_error().decode())
-    return dict(zip(("triangles", "records", "pair_records", "bvh2_nodes", "bvh4_nodes"), [int(x) for x in out]))
+    return dict(zip(("triangles", "bvh2_nodes", "bvh4_nodes", "bvh2_depth", "bvh4_stack"), [int(x) for x in out]))
 
 
 def owned_rows(height: int, params: RtRenderParams) -> list:

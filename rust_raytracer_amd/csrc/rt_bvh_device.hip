@@ -270,7 +270,7 @@ bool build_bvh_device(const double* positions, uint32_t n_positions, const uint3
         nd.c1 = enc[1];
     }
     b.max_depth = max_depth;
-    *out = pack_leaf_records(std::move(b), tri_pos);  // leaves -> records (fan pairs first), slots with holes
+    *out = std::move(b);
     return true;
 }
 

@@ -145,7 +145,7 @@ struct Compiler {
         const RtMesh& m = d.meshes[mi];
         if ((m.n_triangles && (!m.positions || !m.tri_pos || !m.tri_nrm || !m.normals)))
             return fail(RT_E_INVALID, "mesh arrays missing");
-        if (m.n_triangles >= (1u << 24)) return fail(RT_E_UNSUPPORTED, "mesh too large for leaf encoding");
+        if (m.n_triangles >= (1u << 27)) return fail(RT_E_UNSUPPORTED, "mesh too large for leaf encoding");
         for (uint32_t i = 0; i < m.n_triangles * 3; i++) {
             if (m.tri_pos[i] >= m.n_positions || m.tri_nrm[i] >= m.n_normals) return fail(RT_E_INVALID, "triangle index out of range");
             if (m.tri_uv && m.tri_uv[i] >= 0 && (uint32_t(m.tri_uv[i]) >= m.n_uvs || !m.uvs)) return fail(RT_E_INVALID, "uv index out of range");
@@ -178,29 +178,19 @@ struct Compiler {
         *tri_base = uint32_t(out.tris.size());
         *depth = bvh.max_depth;
         out.nodes.insert(out.nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
-        const uint32_t n_slots = uint32_t(bvh.tri_order.size());  // 2 per record
-        if (out.tris.size() + n_slots >= (1ull << 27)) return fail(RT_E_UNSUPPORTED, "meshes too large for leaf encoding");
-        out.n_mesh_triangles += m.n_triangles;
-        out.n_pair_records += bvh.n_pair_records;
-        out.n_records += n_slots / 2;
-        for (uint32_t slot = 0; slot < n_slots; slot++) {
+        for (uint32_t slot = 0; slot < m.n_triangles; slot++) {
             uint32_t t = bvh.tri_order[slot];
-            TriRec<double> r{};
-            TriAttr<double> at{};
-            if (t == kHoleSlot) {  // second half of a single-triangle record: a degenerate triangle no ray can hit (det = 0)
-                out.tris.push_back(r);
-                out.attrs.push_back(at);
-                continue;
-            }
             const double* p0 = m.positions + 3 * size_t(m.tri_pos[3 * size_t(t)]);
             const double* p1 = m.positions + 3 * size_t(m.tri_pos[3 * size_t(t) + 1]);
             const double* p2 = m.positions + 3 * size_t(m.tri_pos[3 * size_t(t) + 2]);
+            TriRec<double> r{};
             for (int a = 0; a < 3; a++) {
                 r.v0[a] = p0[a];
                 r.e1[a] = p1[a] - p0[a];  // mesh.rs:69
                 r.e2[a] = p2[a] - p0[a];  // mesh.rs:70
             }
             out.tris.push_back(r);
+            TriAttr<double> at{};
             const double* n0 = m.normals + 3 * size_t(m.tri_nrm[3 * size_t(t)]);
             const double* n1 = m.normals + 3 * size_t(m.tri_nrm[3 * size_t(t) + 1]);
             const double* n2 = m.normals + 3 * size_t(m.tri_nrm[3 * size_t(t) + 2]);
@@ -216,27 +206,6 @@ struct Compiler {
                 at.uv2[0] = a2[0]; at.uv2[1] = a2[1];
             }
             out.attrs.push_back(at);
-        }
-        // leaf records of the wavefront mesh kernel (layout: rt_scene.h, TriPair)
-        for (uint32_t rec = 0; rec < n_slots / 2; rec++) {
-            const TriRec<double>& A = out.tris[*tri_base + 2 * size_t(rec)];
-            const TriRec<double>& B = out.tris[*tri_base + 2 * size_t(rec) + 1];
-            const bool pair = bvh.tri_order[2 * size_t(rec) + 1] != kHoleSlot;
-            TriPair<double> pr{};
-            for (int a = 0; a < 3; a++) {
-                const int va = (a + 2) % 3;  // v0 is stored as (z, x, y)
-                pr.q[0 + a] = A.e1[a];
-                pr.q[3 + a] = A.v0[va];
-                pr.q[6 + a] = A.e2[a];
-                pr.q[9 + a] = A.v0[va];
-                pr.q[12 + a] = pair ? B.e2[a] : 0.0;
-            }
-            if (pair) {  // the fan property the layout relies on: same first vertex, B's first edge = A's second edge (bit for bit)
-                for (int a = 0; a < 3; a++)
-                    if (std::memcmp(&A.v0[a], &B.v0[a], sizeof(double)) != 0 || std::memcmp(&A.e2[a], &B.e1[a], sizeof(double)) != 0)
-                        return fail(RT_E_INVALID, "internal: a pair record does not hold a triangle fan");
-            }
-            out.pairs.push_back(pr);
         }
         mesh_geometry[mi] = {*node_base, *tri_base};
         mesh_depth[mi] = bvh.max_depth;

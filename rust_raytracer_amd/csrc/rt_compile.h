@@ -24,10 +24,8 @@ struct CompiledScene {
     std::vector<BuildNode4> nodes4;          // 4-wide collapse, relative to MeshInst::node4_base
     std::vector<Bounds<double>> mesh_bounds; // per MeshInst
     uint32_t max_bvh4_stack = 1;
-    std::vector<TriRec<double>> tris;        // per slot (2 per record, leaf order; holes are zero)
-    std::vector<TriPair<double>> pairs;      // per record
-    std::vector<TriAttr<double>> attrs;      // per slot
-    uint64_t n_mesh_triangles = 0, n_pair_records = 0, n_records = 0;  // over all distinct meshes (diagnostics)
+    std::vector<TriRec<double>> tris;        // leaf order
+    std::vector<TriAttr<double>> attrs;      // same order
     std::vector<MaterialRec> materials;
     std::vector<MaterialParams<double>> material_params;
     std::vector<TextureRec<double>> textures;  // postfix ops of every texture program (see rt_scene.h)

@@ -280,7 +280,7 @@ RT_DEV void mesh_traverse(const SceneView<R>& sc, const MeshInst& mi, const Ray<
             if (h1) { cur = c1; continue; }
         } else {
             uint32_t code = uint32_t(~cur);
-            uint32_t first = code >> 4, count = (code & 15u) + 1u;  // slots; holes are degenerate records (det = 0: culled)
+            uint32_t first = code >> 3, count = (code & 7u) + 1u;
             for (uint32_t i = 0; i < count; i++) {
                 const TriRec<R>& tr = tris[first + i];
                 if (STATS) cnt.tri_tests++;

@@ -314,9 +314,6 @@ struct DeviceScene {
             cast_arr(tris[i].v0, cs.tris[i].v0); cast_arr(tris[i].e1, cs.tris[i].e1); cast_arr(tris[i].e2, cs.tris[i].e2);
             tris[i]._pad = R(0);
         }
-        std::vector<TriPair<R>> pairs(cs.pairs.size());
-        for (size_t i = 0; i < pairs.size(); i++)
-            for (int k = 0; k < 16; k++) pairs[i].q[k] = R(cs.pairs[i].q[k]);
         std::vector<TriAttr<R>> attrs(cs.attrs.size());
         for (size_t i = 0; i < attrs.size(); i++) {
             const auto& s = cs.attrs[i];
@@ -361,7 +358,6 @@ struct DeviceScene {
         if ((st = buf.upload(nodes4, &view.nodes4)) != RT_OK) return st;
         if ((st = buf.upload(mesh_bounds, &view.mesh_bounds)) != RT_OK) return st;
         if ((st = buf.upload(tris, &view.tris)) != RT_OK) return st;
-        if ((st = buf.upload(pairs, &view.pairs)) != RT_OK) return st;
         if ((st = buf.upload(attrs, &view.attrs)) != RT_OK) return st;
         if ((st = buf.upload(cs.materials, &view.materials)) != RT_OK) return st;
         if ((st = buf.upload(mparams, &view.material_params)) != RT_OK) return st;
@@ -606,7 +602,11 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     const uint32_t T = p.thread_count;
     const uint64_t per_replica = uint64_t(strata) * npix;
     // pool size: enough paths to keep every CU busy for several rounds per launch
-    uint32_t capacity = env_u32("RT_WF_POOL", 1u << 25);  // 32M paths (5.5 GB of f64 state); measured at full size: 2M 322, 8M 377, 16M 393, 32M 404 Msamples/s
+    // 64M paths (9.6 GB of f64 state).  Measured at full size, round 2 (k_wf_mesh ms per step / Msamples/s): 16M 789 / 1067,
+    // 32M 731 / 1115, 64M 699 / 1144, 128M 686 / 1153, 256M 682 / 1128: every launch of the persistent mesh kernel ends with
+    // a drain of ~0.4 ms (the longest remaining traversals, dependent fetches), so fewer, larger launches win until the pool's
+    // own streams get slower.
+    uint32_t capacity = env_u32("RT_WF_POOL", 1u << 26);
     if (capacity > (1u << 28)) capacity = 1u << 28;  // the kernels address pool arrays through 32-bit byte offsets (rt_wavefront.h, at())
     if (uint64_t(capacity) > per_replica * T) capacity = uint32_t(per_replica * T);
     if (capacity < 64) capacity = 64;
@@ -841,8 +841,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     st.tri_tests = hc.tri_tests;
     st.prim_tests = hc.prim_tests;
     st.bytes_node = split ? sizeof(BvhNode4f) : sizeof(BvhNode<R>);
-    st.bytes_tri = split ? sizeof(TriPair<R>) : sizeof(TriRec<R>);
-    st.leaf_records = split ? hc.leaf_records : 0;
+    st.bytes_tri = sizeof(TriRec<R>);
     st.bytes_attr = sizeof(TriAttr<R>);
     // path state moved by the DOMINANT kernel per ray it traverses: ray (6 R) + bound/op read (R + 4)
     // + hit written when a triangle wins (3 R + 8) + queue entry (4)
@@ -1054,11 +1053,11 @@ int rt_scene_mesh_stats(const RtSceneDesc* desc, uint64_t out[5]) {
     std::string err;
     int st = compile_scene(desc, &cs, &err, CompileOptions());
     if (st != RT_OK) return set_err(st, err);
-    out[0] = cs.n_mesh_triangles;
-    out[1] = cs.n_records;
-    out[2] = cs.n_pair_records;
-    out[3] = cs.nodes.size();
-    out[4] = cs.nodes4.size();
+    out[0] = cs.tris.size();
+    out[1] = cs.nodes.size();
+    out[2] = cs.nodes4.size();
+    out[3] = cs.max_bvh_depth;
+    out[4] = cs.max_bvh4_stack;
     return RT_OK;
 }
 

@@ -80,7 +80,7 @@ struct VolumeRec {  // volume.rs:15-19
 
 struct MeshInst {
     uint32_t node_base;  // first BVH node of this mesh in nodes[]
-    uint32_t tri_base;   // first triangle SLOT in tris[] / attrs[] (always even; record r of the mesh = slots tri_base + 2 r, + 2 r + 1)
+    uint32_t tri_base;   // first triangle record in tris[] / attrs[]
     int32_t material;
     uint32_t flags;      // RT_MESH_* | MESH_HAS_UV
     uint32_t n_tris;
@@ -92,7 +92,7 @@ constexpr uint32_t MESH_HAS_UV = 0x100u;
 
 // BVH2 node: the two children's boxes live in the parent, so one fetch decides both.
 // child >= 0: inner node index (relative to node_base); child < 0: leaf,
-// ~child = (first_slot << 4) | (slots - 1) (slots relative to tri_base; holes are degenerate records); kEmptyChild: no child.
+// ~child = (first_tri << 3) | (count - 1); kEmptyChild: no child.
 constexpr int32_t kEmptyChild = INT32_MIN;
 template <typename R>
 struct alignas(sizeof(R) == 8 ? 128 : 64) BvhNode {
@@ -107,11 +107,9 @@ struct alignas(sizeof(R) == 8 ? 128 : 64) BvhNode {
 // hit is ever skipped.  Used by the wavefront mesh kernel for both arithmetic types.
 struct alignas(128) BvhNode4f {
     float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
-    int32_t child[4];  // >= 0 inner node (relative to node4_base), kEmptyChild, or leaf:
-                       // ~child = (first_record << 6) | ((records - 1) << 3) | (triangles - 1), records relative to tri_base / 2
+    int32_t child[4];  // >= 0 inner node (relative to node4_base), < 0 leaf code, kEmptyChild
     uint32_t _pad[4];
 };
-constexpr uint32_t kLeaf4RecShift = 6;
 
 // Triangle record for the intersection test: v0 and the two edges (mesh.rs:69-70 computes the
 // edges per test; v1 - v0 done once on the host in the same arithmetic gives the same bits).
@@ -119,18 +117,6 @@ template <typename R>
 struct alignas(16) TriRec {
     R v0[3], e1[3], e2[3];
     R _pad;
-};
-// Leaf record of the wavefront mesh kernel: ONE or TWO triangles in one aligned cache line (128 B in f64, 64 B in
-// f32).  Two triangles share a record when they are a fan in their own vertex order, A = (a, b, c), B = (a, c, d):
-// B's first edge c - a is A's second edge, so the record holds v0 = a and the edges e1 = b - a, e2 = c - a, e3 = d - a
-// (each exactly the subtraction mesh.rs:69-70 performs).  The layout repeats v0 so that triangle s reads the SAME ten
-// values from offset 6 s:   e1.x e1.y e1.z | v0.z v0.x v0.y | e2.x e2.y e2.z | v0.z v0.x v0.y | e3.x e3.y e3.z | 0
-//                           s = 0: first edge = [0..3), v0 = [3..6), second edge = [6..9)
-//                           s = 1: first edge = [6..9), v0 = [9..12), second edge = [12..15)
-// A TriRec fetch (80 B, 16-B aligned) straddled 1.5 lines on average; a pair now costs one line request for two tests.
-template <typename R>
-struct alignas(16 * sizeof(R)) TriPair {
-    R q[16];
 };
 // Shading attributes, fetched only for the final closest hit.
 template <typename R>
@@ -207,9 +193,8 @@ struct SceneView {
     const BvhNode<R>* nodes;
     const BvhNode4f* nodes4;       // 4-wide f32 nodes (wavefront mesh kernel)
     const Bounds<R>* mesh_bounds;  // per mesh instance: exact box of its triangles (object space)
-    const TriRec<R>* tris;          // per SLOT (BVH2 kernels, flat shading, tangent frames); holes are all-zero (never hit)
-    const TriPair<R>* pairs;        // per RECORD (= slot pair): wavefront mesh kernel
-    const TriAttr<R>* attrs;        // per SLOT
+    const TriRec<R>* tris;
+    const TriAttr<R>* attrs;
     const MaterialRec* materials;
     const MaterialParams<R>* material_params;
     const TextureRec<R>* textures;   // postfix ops
@@ -252,7 +237,6 @@ struct DeviceCounters {
     // k_wf_mesh lane utilisation (collect_stats): wave-level iterations of the node / triangle / refill code and
     // the lanes that were active in them (utilisation = lanes / (64 * waves)); printed with RT_WF_DEBUG=1
     unsigned long long node_wave_iters, tri_wave_iters, refill_wave_iters, refill_lanes, pops_culled;
-    unsigned long long leaf_records;  // k_wf_mesh: leaf records (one cache line each) of the leaves visited
 };
 
 }  // namespace rt

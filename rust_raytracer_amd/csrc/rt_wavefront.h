@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<
                     else if (h1) { node = c1; pop = false; }
                 } else {
                     uint32_t code = uint32_t(~node);
-                    uint32_t first = code >> 4, count = (code & 15u) + 1u;  // slots; holes are degenerate records (det = 0: culled)
+                    uint32_t first = code >> 3, count = (code & 7u) + 1u;
                     for (uint32_t i = 0; i < count; i++) {
                         const TriRec<R>& tr = tris[first + i];
                         if (STATS) cnt.tri_tests++;
@@ -612,12 +612,12 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
     const MeshInst mi = sc.meshes[mop.arg];
     const Bounds<R> rb = sc.mesh_bounds[mop.arg];
     const BvhNode4f* nodes = sc.nodes4 + mi.node4_base;
-    const TriPair<R>* pairs = sc.pairs + mi.tri_base / 2u;
+    const TriRec<R>* tris = sc.tris + mi.tri_base;
     const bool hit_back = (mi.flags & RT_MESH_HIT_BACK_FACES) != 0;
     const R big = sizeof(R) == 8 ? R(1e150) : R(1e18);
 
     LaneCounters cnt;
-    uint32_t w_node = 0, w_tri = 0, w_refill = 0, l_refill = 0, l_culled = 0, l_recs = 0;  // STATS: see DeviceCounters
+    uint32_t w_node = 0, w_tri = 0, w_refill = 0, l_refill = 0, l_culled = 0;  // STATS: see DeviceCounters
     bool has = false;
     bool exhausted = false;
     bool found = false;      // a triangle closer than the other primitives' hit was found
@@ -759,18 +759,13 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
         // ---- leaves: the (lane, triangle) pairs of all lanes that hold a leaf are FLATTENED over the wave, so
         //      that 64 triangle tests run per pass whatever the leaf sizes are (a per-lane loop ran at 33 % lane
         //      utilisation: leaves hold 1..4 triangles and a third of the lanes hold none).  Every pass: pair w ->
-        //      (owner lane, slot in leaf) through a wave-private LDS table, the owner's ray through cross-lane reads,
-        //      one exact test in R on the ten values of its half of a leaf RECORD (rt_scene.h, TriPair: one aligned
-        //      line holds a fan of two triangles), result into LDS; the owners then take their results with the
-        //      reference's interval rule (mesh.rs:62-107: strictly nearer wins, so among equal t the lowest slot
-        //      does — made explicit here, the results of one leaf arrive pair records first). ----
+        //      (owner lane, k) through a wave-private LDS table, the owner's ray through cross-lane reads, one exact
+        //      test in R, result into LDS; the owners then take their results in k order with the reference's
+        //      interval rule, which makes the outcome identical to the sequential loop (mesh.rs:62-107). ----
         {
             const bool leaf = has && node < 0;
             const uint32_t code = uint32_t(~node);
-            const uint32_t first_rec = leaf ? (code >> kLeaf4RecShift) : 0u;
-            const uint32_t n_rec = ((code >> 3) & 7u) + 1u;
-            const uint32_t count = leaf ? ((code & 7u) + 1u) : 0u;   // triangles
-            const uint32_t n_two = count - (leaf ? n_rec : 0u);       // records that hold two: they come first
+            const uint32_t first = leaf ? (code >> 3) : 0u, count = leaf ? ((code & 7u) + 1u) : 0u;
             uint32_t pre = 0, total = 0;
 #pragma unroll
             for (int bit = 0; bit < 4; bit++) {
@@ -779,37 +774,32 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
                 total += uint32_t(__popcll(m)) << bit;
             }
             if (total != 0u) {
-                // triangle j of the leaf -> slot within the leaf (2 x record + half)
-                auto slot_of = [&](uint32_t j) { return j < 2u * n_two ? j : 2u * (j - n_two); };
                 for (uint32_t j = 0; j < 8u; j++) {
                     if (__ballot(j < count) == 0ull) break;
-                    if (j < count) pair_tbl[pre + j] = uint16_t(lane | (slot_of(j) << 8));
+                    if (j < count) pair_tbl[pre + j] = uint16_t(lane | (j << 8));
                 }
                 __builtin_amdgcn_wave_barrier();
-                bool set_here = false;  // this lane's current hit was found in THIS leaf (ties go to the lower slot)
                 for (uint32_t c0 = 0; c0 < total; c0 += 64u) {
                     if (STATS) w_tri++;
                     const uint32_t w = c0 + lane;
                     const bool act = w < total;
                     const uint32_t e = act ? uint32_t(pair_tbl[w]) : 0u;
                     const int owner = int(e & 0xFFu);
-                    const uint32_t q = e >> 8;  // slot within the owner's leaf
+                    const uint32_t k = e >> 8;
                     const V3<R> po = {__shfl(o.x, owner), __shfl(o.y, owner), __shfl(o.z, owner)};
                     const V3<R> pd = {__shfl(d.x, owner), __shfl(d.y, owner), __shfl(d.z, owner)};
-                    const uint32_t pfirst = uint32_t(__shfl(int(first_rec), owner));
-                    R rt = Lim<R>::inf(), ru = R(0), rv = R(0);  // t = +inf: "no hit" (fails `t < t_max` at the owner)
+                    const uint32_t pfirst = uint32_t(__shfl(int(first), owner));
+                    R rt = Lim<R>::inf(), ru = R(0), rv = R(0);  // t = +inf: "no hit" (fails `t_max <= t` at the owner)
                     if (act) {
-                        using R2 = typename std::conditional<sizeof(R) == 8, double2, float2>::type;
-                        const R2* rec = reinterpret_cast<const R2*>(pairs[pfirst + (q >> 1)].q + 6u * (q & 1u));
-                        const R2 r01 = rec[0], r23 = rec[1], r45 = rec[2], r67 = rec[3], r89 = rec[4];
+                        const TriRec<R>& tr = tris[pfirst + k];
                         if (STATS) cnt.tri_tests++;
-                        const V3<R> edge1 = {r01.x, r01.y, r23.x}, v0 = {r45.x, r45.y, r23.y}, edge2 = {r67.x, r67.y, r89.x};
+                        V3<R> edge1 = ld3(tr.e1), edge2 = ld3(tr.e2);
                         V3<R> ray_x_edge2 = cross(pd, edge2);
                         R det = dot(edge1, ray_x_edge2);
                         R dd = hit_back ? fabs(det) : det;
                         if (!(dd < Lim<R>::eps())) {
                             R inv_det = R(1) / det;
-                            V3<R> b = po - v0;
+                            V3<R> b = po - ld3(tr.v0);
                             R u = dot(b, ray_x_edge2) * inv_det;
                             if (!(u < R(0) || u > R(1))) {
                                 V3<R> b_x_edge1 = cross(b, edge1);
@@ -830,19 +820,15 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
                         for (int j = jlo; j < jhi; j++) {
                             const int idx = int(pre) + j - int(c0);
                             const R t = res_t[idx];
-                            if (t <= t_lo) continue;
-                            const int32_t slot_abs = int32_t(mi.tri_base + 2u * first_rec + slot_of(uint32_t(j)));
-                            if (t_max <= t && !(set_here && t == t_max && slot_abs < hit_tri)) continue;
+                            if (t <= t_lo || t_max <= t) continue;
                             t_max = t; hit_u = res_u[idx]; hit_v = res_v[idx];
-                            hit_tri = slot_abs;
+                            hit_tri = int32_t(mi.tri_base + first + uint32_t(j));
                             found = true;
-                            set_here = true;
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
                 if (leaf) {
-                    if (STATS) l_recs += n_rec;
                     tmax32 = f32_at_least(t_max - t_shift);
                     pop_next();
                 }
@@ -855,7 +841,6 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
         atomicAdd(&counters->tri_tests, (unsigned long long)cnt.tri_tests);
         atomicAdd(&counters->refill_lanes, (unsigned long long)l_refill);
         atomicAdd(&counters->pops_culled, (unsigned long long)l_culled);
-        atomicAdd(&counters->leaf_records, (unsigned long long)l_recs);
         uint32_t wn = w_node, wt = w_tri, wr = w_refill;  // wave-uniform
         if ((threadIdx.x & 63u) == 0) {
             atomicAdd(&counters->node_wave_iters, (unsigned long long)wn);

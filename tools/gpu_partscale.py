@@ -26,7 +26,7 @@ def run(n, pool):
     return time.perf_counter() - t0
 base = None
 for n in (1, 2, 4, 8):
-    for pool in (0, 1 << 24, 1 << 23, 1 << 22):
+    for pool in (0, 1 << 25, 1 << 24, 1 << 23):
         if n == 1 and pool: continue
         t = run(n, pool)
         if n == 1: base = t
