@@ -277,8 +277,9 @@ int rt_debug_trace_sample(const RtScene* scene, const RtCameraDesc* camera, cons
 #define RT_SCENE_INFO_VOLUMES 4u
 int rt_scene_info(const RtSceneDesc* desc, uint32_t* flags_out);
 /* Same, plus mesh statistics of the compiled scene (distinct meshes, host-built BVH):
- * out[0] triangle records, out[1] BVH2 nodes, out[2] 4-wide nodes, out[3] BVH2 depth, out[4] worst-case 4-wide traversal stack. */
-int rt_scene_mesh_stats(const RtSceneDesc* desc, uint64_t out[5]);
+ * out[0] triangle records, out[1] BVH2 nodes, out[2] 4-wide nodes, out[3] BVH2 depth, out[4] worst-case 4-wide traversal stack,
+ * out[5] scene-program ops, out[6] sphere / quad groups re-built as SAH trees, out[7] primitives in them. */
+int rt_scene_mesh_stats(const RtSceneDesc* desc, uint64_t out[8]);
 
 /* Message for the last non-RT_OK status on this thread ("" if none). */
 const char* rt_last_error(void);

@@ -237,11 +237,12 @@ def scene_info(desc) -> int:
 def scene_mesh_stats(desc) -> dict:
     """rt_scene_mesh_stats: triangle records / BVH node counts / depths (host only)."""
     lib = load_device_lib()
-    out = (C.c_uint64 * 5)()
+    out = (C.c_uint64 * 8)()
     st = lib.rt_scene_mesh_stats(desc, out)
     if st != RT_OK:
         raise RtError(st, lib.rt_last_error().decode())
-    return dict(zip(("triangles", "bvh2_nodes", "bvh4_nodes", "bvh2_depth", "bvh4_stack"), [int(x) for x in out]))
+    return dict(zip(("triangles", "bvh2_nodes", "bvh4_nodes", "bvh2_depth", "bvh4_stack", "ops", "rebuilt_groups", "rebuilt_prims"),
+                    [int(x) for x in out]))
 
 
 def owned_rows(height: int, params: RtRenderParams) -> list:

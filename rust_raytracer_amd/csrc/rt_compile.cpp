@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 
 namespace rt {
@@ -58,7 +59,187 @@ struct Compiler {
         return id;
     }
 
-    void emit(int32_t type, int32_t arg) { out.ops.push_back({type, arg, 0, chain_id()}); }
+    int32_t next_rank = 1;  // reference visiting order of the hit-producing ops (Op::skip)
+    void emit(int32_t type, int32_t arg) {
+        int32_t rank = 0;
+        switch (type) {
+            case OP_SPHERE: case OP_PLANE: case OP_MESH: case OP_SKY: case OP_SUN: case OP_VOL_END: rank = next_rank++; break;
+            default: break;
+        }
+        out.ops.push_back({type, arg, rank, chain_id()});
+    }
+
+    // ---- primitive groups: an object-BVH / list subtree made of spheres and quads only is re-built ----
+    // The reference's own object BVH (bvh.rs:32-82: random axis, median split by the boxes' minima, one object + a
+    // NullObject per leaf) is walked depth-first in a fixed order; as skip-pointer ops it costs every lane ~100 serial,
+    // divergent steps on the default scene's 440-sphere field.  Only WHICH primitives a ray can reach and which of them
+    // is hit first matters for the result, so the subtree is replaced by a binned-SAH tree over the same primitives,
+    // emitted as the same kind of ops (OP_BOUNDS with skip pointers; no kernel change):
+    //   * boxes of the new tree = unions of the primitives' GEOMETRIC boxes (sphere: centre -+ |r|; quad: the
+    //     reference's own box), min / max of the reference's numbers only;
+    //   * a reference ancestor box that does not contain a primitive's geometric box can cull real hits (SURVEY B-8:
+    //     a negative-radius sphere has an inverted box, and the union with it is only partial): such boxes stay in
+    //     front of that primitive as GUARD ops (a box test only asks whether the ray meets the box ahead of t_lo, so it
+    //     gives the same verdict wherever in the order it is asked); a primitive behind a box no ray can pass
+    //     (inverted / NaN) is unreachable in the reference and is dropped;
+    //   * ties at exactly equal t go to the primitive the reference visits first: Op::skip = rank (hit_takes_over).
+    struct GroupPrim {
+        uint32_t node;
+        int32_t rank_order;            // position in the reference's depth-first order inside the group
+        double lo[3], hi[3];           // geometric box
+        std::vector<int32_t> guards;   // indices into out.bounds, outermost first
+    };
+    struct BoxD { double lo[3], hi[3]; };
+    static bool box_passable(const BoxD& b) {
+        for (int a = 0; a < 3; a++) if (!(b.lo[a] <= b.hi[a])) return false;  // inverted or NaN: the slab test never passes
+        return true;
+    }
+    static bool box_contains(const BoxD& outer, const double* lo, const double* hi) {
+        for (int a = 0; a < 3; a++) if (!(outer.lo[a] <= lo[a] && hi[a] <= outer.hi[a])) return false;
+        return true;
+    }
+    // Collects the primitives under `node` in the reference's order; false if the subtree holds anything else.
+    bool collect_group(uint32_t node, int depth, std::vector<BoxD>& ancestors, std::vector<GroupPrim>& prims, int* order) {
+        if (node >= d.n_nodes || depth > 512) return false;
+        const RtNode& n = d.nodes[node];
+        if (uint64_t(n.first_child) + n.n_children > d.n_child_indices) return false;
+        switch (n.type) {
+            case RT_NODE_NULL:
+                return true;
+            case RT_NODE_LIST:
+            case RT_NODE_BVH: {
+                if (n.type == RT_NODE_BVH && n.n_children != 2) return false;
+                const bool check = n.type == RT_NODE_BVH || !(n.flags & RT_LIST_DISABLE_BOUNDS_CHECK);
+                if (check) {
+                    BoxD b;
+                    for (int a = 0; a < 3; a++) { b.lo[a] = n.bounds[a]; b.hi[a] = n.bounds[3 + a]; }
+                    ancestors.push_back(b);
+                }
+                bool ok = true;
+                for (uint32_t k = 0; ok && k < n.n_children; k++) ok = collect_group(d.child_indices[n.first_child + k], depth + 1, ancestors, prims, order);
+                if (check) ancestors.pop_back();
+                return ok;
+            }
+            case RT_NODE_SPHERE:
+            case RT_NODE_PLANE: {
+                GroupPrim p;
+                p.node = node;
+                if (n.type == RT_NODE_SPHERE) {
+                    const double r = std::fabs(n.p[3]);
+                    for (int a = 0; a < 3; a++) { p.lo[a] = n.p[a] - r; p.hi[a] = n.p[a] + r; }
+                } else {
+                    for (int a = 0; a < 3; a++) { p.lo[a] = n.bounds[a]; p.hi[a] = n.bounds[3 + a]; }
+                }
+                for (int a = 0; a < 3; a++) if (!(p.lo[a] <= p.hi[a]) || !std::isfinite(p.lo[a]) || !std::isfinite(p.hi[a])) return false;
+                bool reachable = true;
+                for (const BoxD& b : ancestors) {
+                    if (!box_passable(b)) { reachable = false; break; }
+                    if (!box_contains(b, p.lo, p.hi)) {
+                        Bounds<double> g;
+                        for (int a = 0; a < 3; a++) { g.lo[a] = b.lo[a]; g.hi[a] = b.hi[a]; }
+                        out.bounds.push_back(g);
+                        p.guards.push_back(int32_t(out.bounds.size()) - 1);
+                    }
+                }
+                if (reachable) {  // (otherwise the reference never reaches it: it takes part in nothing)
+                    p.rank_order = (*order)++;
+                    prims.push_back(std::move(p));
+                }
+                return true;
+            }
+            default:
+                return false;
+        }
+    }
+
+    // Emits the SAH tree over prims[begin, end) (indices in `idx`); leaves hold one or two primitives.
+    void emit_group_tree(std::vector<GroupPrim>& prims, std::vector<uint32_t>& idx, size_t begin, size_t end, int32_t rank_base) {
+        BoxD box;
+        for (int a = 0; a < 3; a++) { box.lo[a] = HUGE_VAL; box.hi[a] = -HUGE_VAL; }
+        for (size_t i = begin; i < end; i++)
+            for (int a = 0; a < 3; a++) {
+                box.lo[a] = std::fmin(box.lo[a], prims[idx[i]].lo[a]);
+                box.hi[a] = std::fmax(box.hi[a], prims[idx[i]].hi[a]);
+            }
+        Bounds<double> b;
+        for (int a = 0; a < 3; a++) { b.lo[a] = box.lo[a]; b.hi[a] = box.hi[a]; }
+        out.bounds.push_back(b);
+        const size_t bounds_op = out.ops.size();
+        emit(OP_BOUNDS, int32_t(out.bounds.size()) - 1);
+        const size_t n = end - begin;
+        if (n <= 2) {
+            for (size_t i = begin; i < end; i++) {
+                const GroupPrim& p = prims[idx[i]];
+                std::vector<size_t> guard_ops;
+                for (int32_t g : p.guards) { guard_ops.push_back(out.ops.size()); emit(OP_BOUNDS, g); }
+                const RtNode& nd = d.nodes[p.node];
+                if (nd.type == RT_NODE_SPHERE) emit(OP_SPHERE, sphere_index(p.node));
+                else emit(OP_PLANE, plane_index(p.node));
+                out.ops.back().skip = rank_base + p.rank_order;  // the reference's visiting order, not the emission order
+                for (size_t go : guard_ops) out.ops[go].skip = int32_t(out.ops.size());
+            }
+        } else {
+            // best split of the three sorted sweeps (surface area heuristic on the geometric boxes)
+            auto area = [](const BoxD& x) { double dx = x.hi[0] - x.lo[0], dy = x.hi[1] - x.lo[1], dz = x.hi[2] - x.lo[2]; return dx * dy + dy * dz + dz * dx; };
+            double best_cost = HUGE_VAL;
+            int best_axis = 0;
+            size_t best_k = n / 2;
+            std::vector<double> right_area(n);
+            for (int axis = 0; axis < 3; axis++) {
+                std::sort(idx.begin() + begin, idx.begin() + end, [&](uint32_t x, uint32_t y) {
+                    const double cx = prims[x].lo[axis] + prims[x].hi[axis], cy = prims[y].lo[axis] + prims[y].hi[axis];
+                    return cx < cy || (cx == cy && x < y);
+                });
+                BoxD acc;
+                for (int a = 0; a < 3; a++) { acc.lo[a] = HUGE_VAL; acc.hi[a] = -HUGE_VAL; }
+                for (size_t k = n; k-- > 1;) {
+                    const GroupPrim& p = prims[idx[begin + k]];
+                    for (int a = 0; a < 3; a++) { acc.lo[a] = std::fmin(acc.lo[a], p.lo[a]); acc.hi[a] = std::fmax(acc.hi[a], p.hi[a]); }
+                    right_area[k] = area(acc);
+                }
+                for (int a = 0; a < 3; a++) { acc.lo[a] = HUGE_VAL; acc.hi[a] = -HUGE_VAL; }
+                for (size_t k = 1; k < n; k++) {
+                    const GroupPrim& p = prims[idx[begin + k - 1]];
+                    for (int a = 0; a < 3; a++) { acc.lo[a] = std::fmin(acc.lo[a], p.lo[a]); acc.hi[a] = std::fmax(acc.hi[a], p.hi[a]); }
+                    const double cost = area(acc) * double(k) + right_area[k] * double(n - k);
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_k = k; }
+                }
+            }
+            std::sort(idx.begin() + begin, idx.begin() + end, [&](uint32_t x, uint32_t y) {
+                const double cx = prims[x].lo[best_axis] + prims[x].hi[best_axis], cy = prims[y].lo[best_axis] + prims[y].hi[best_axis];
+                return cx < cy || (cx == cy && x < y);
+            });
+            emit_group_tree(prims, idx, begin, begin + best_k, rank_base);
+            emit_group_tree(prims, idx, begin + best_k, end, rank_base);
+        }
+        out.ops[bounds_op].skip = int32_t(out.ops.size());
+    }
+
+    // Tries to compile the subtree under `node` as a re-built primitive group; false = compile it op by op as usual.
+    bool try_emit_group(uint32_t node, int depth) {
+        if (!opt.rebuild_prim_groups) return false;
+        const size_t bounds_mark = out.bounds.size();
+        std::vector<BoxD> ancestors;
+        std::vector<GroupPrim> prims;
+        int order = 0;
+        if (!collect_group(node, depth, ancestors, prims, &order) || prims.size() < 12) {
+            out.bounds.resize(bounds_mark);  // guard boxes of an abandoned attempt
+            return false;
+        }
+        // materialise the primitive tables in the reference's order (sphere / plane indices are handed out on first use)
+        for (const GroupPrim& p : prims) {
+            int32_t i = d.nodes[p.node].type == RT_NODE_SPHERE ? sphere_index(p.node) : plane_index(p.node);
+            if (i < 0) return true;  // status is set: compile fails
+        }
+        std::vector<uint32_t> idx(prims.size());
+        for (size_t i = 0; i < idx.size(); i++) idx[i] = uint32_t(i);
+        const int32_t rank_base = next_rank;
+        next_rank += int32_t(prims.size());
+        emit_group_tree(prims, idx, 0, prims.size(), rank_base);
+        out.n_rebuilt_groups++;
+        out.n_rebuilt_prims += uint32_t(prims.size());
+        return true;
+    }
 
     bool check_material(int32_t m) {
         if (m < 0 || uint32_t(m) >= d.n_materials) return fail(RT_E_INVALID, "material index out of range");
@@ -263,6 +444,7 @@ struct Compiler {
             case RT_NODE_LIST:
             case RT_NODE_BVH: {
                 if (n.type == RT_NODE_BVH && n.n_children != 2) return fail(RT_E_INVALID, "bvh node needs two children");
+                if (!in_volume && try_emit_group(node, depth)) return status == RT_OK;
                 size_t bounds_op = SIZE_MAX;
                 bool check = n.type == RT_NODE_BVH || !(n.flags & RT_LIST_DISABLE_BOUNDS_CHECK);
                 if (check) {

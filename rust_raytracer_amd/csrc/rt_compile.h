@@ -43,10 +43,12 @@ struct CompiledScene {
     // the light set rules that out (see Compiler::decide_zero_weight_stop); the kernels then end zero-weight paths,
     // otherwise they trace them to the end like the reference.
     bool zero_weight_stop = false;
+    uint32_t n_rebuilt_groups = 0, n_rebuilt_prims = 0;  // object-BVH / list subtrees re-built as SAH trees (rt_compile.cpp)
 };
 
 struct CompileOptions {
     bool bvh_on_device = false;  // build mesh BVHs with rt_bvh_device.hip (the HIP device must already be selected)
+    bool rebuild_prim_groups = true;  // re-build sphere / quad subtrees of >= 12 primitives (RT_PRIM_REBUILD=0 keeps the reference's tree)
 };
 
 // Returns RT_OK or a negative RtStatus with `err` set.

@@ -182,8 +182,9 @@ template <typename R> RT_DEV bool test_bounding_box(const Bounds<R>& b, const Ra
 }
 
 // ------------------------------------------------------------------ primitives
-// sphere.rs:40-62: nearest root in (t_lo, t_hi), un-normalised direction
-template <typename R> RT_DEV bool sphere_test(const SpherePrim<R>& s, const Ray<R>& ray, R t_lo, R t_hi, R& t_out) {
+// sphere.rs:40-62: nearest root in (t_lo, t_hi), un-normalised direction.  INCL: t_hi itself is accepted as well (the scene
+// program decides ties by the reference's visiting order, see hit_takes_over).
+template <typename R, bool INCL = false> RT_DEV bool sphere_test(const SpherePrim<R>& s, const Ray<R>& ray, R t_lo, R t_hi, R& t_out) {
     V3<R> center_diff = ray.o - ld3(s.center);
     R a = length_squared(ray.d);
     R half_b = dot(ray.d, center_diff);
@@ -192,23 +193,23 @@ template <typename R> RT_DEV bool sphere_test(const SpherePrim<R>& s, const Ray<
     if (discriminant < R(0)) return false;
     R d_sqrt = sqrt(discriminant);
     R root = (-half_b - d_sqrt) / a;
-    if (root <= t_lo || t_hi <= root) {
+    if (root <= t_lo || (INCL ? t_hi < root : t_hi <= root)) {
         root = (-half_b + d_sqrt) / a;
-        if (root <= t_lo || t_hi <= root) return false;
+        if (root <= t_lo || (INCL ? t_hi < root : t_hi <= root)) return false;
     }
     t_out = root;
     return true;
 }
 
 // plane.rs:66-89
-template <typename R> RT_DEV bool plane_test(const PlanePrim<R>& p, const Ray<R>& ray, R t_lo, R t_hi, R& t_out, R& u_out, R& v_out) {
+template <typename R, bool INCL = false> RT_DEV bool plane_test(const PlanePrim<R>& p, const Ray<R>& ray, R t_lo, R t_hi, R& t_out, R& u_out, R& v_out) {
     V3<R> normal = ld3(p.normal);
     R dot_ray_normal = dot(normal, ray.d);
     R dd = p.backface ? fabs(dot_ray_normal) : -dot_ray_normal;
     if (dd < Lim<R>::eps()) return false;
     V3<R> corner = ld3(p.corner);
     R hit_t = dot(normal, corner - ray.o) / dot_ray_normal;
-    if (hit_t <= t_lo || t_hi <= hit_t) return false;
+    if (hit_t <= t_lo || (INCL ? t_hi < hit_t : t_hi <= hit_t)) return false;
     V3<R> hit_pos = ray_at(ray, hit_t);
     V3<R> local_pos = hit_pos - corner;
     R u = dot(local_pos, ld3(p.inv_u));
@@ -228,6 +229,16 @@ struct Best {
     int32_t tri;  // mesh hits: triangle slot (absolute index into tris/attrs)
     R u, v;       // mesh: barycentrics; plane: (u, v)
 };
+
+// Closest-hit bookkeeping of the scene program for sphere / quad ops.  Their tests run with the upper end of the interval
+// INCLUDED; a candidate at exactly the current closest distance takes over only if the reference would have visited it
+// first (its tests use strict `t < closest`, list.rs:58-74, bvh.rs:84-101: the first one visited wins).  Op::skip of a
+// primitive op is its RANK in the reference's depth-first order: the ops of a rebuilt primitive group (rt_compile.cpp)
+// are not in that order; everywhere else rank order is program order and this rule changes nothing.
+template <typename R> RT_DEV bool hit_takes_over(const SceneView<R>& sc, R t, const Op& op, const Best<R>& best) {
+    if (!(t == best.t)) return true;  // strictly nearer (or NaN, which the reference's interval test lets through as well)
+    return best.pc >= 0 && op.skip < sc.ops[best.pc].skip;
+}
 
 struct LaneCounters {
     uint32_t rays = 0, mesh_rays = 0, node_visits = 0, tri_tests = 0, prim_tests = 0;
@@ -413,7 +424,7 @@ RT_DEV void world_test(const SceneView<R>& sc, const Ray<R>& wray, const R t_lo_
             case OP_SPHERE: {
                 R t;
                 if (STATS) cnt.prim_tests++;
-                if (sphere_test(sc.spheres[op.arg], cur, t_lo, best.t, t)) {
+                if (sphere_test<R, true>(sc.spheres[op.arg], cur, t_lo, best.t, t) && hit_takes_over(sc, t, op, best)) {
                     best.t = t;
                     best.pc = pc;
                 }
@@ -422,7 +433,7 @@ RT_DEV void world_test(const SceneView<R>& sc, const Ray<R>& wray, const R t_lo_
             case OP_PLANE: {
                 R t, u, v;
                 if (STATS) cnt.prim_tests++;
-                if (plane_test(sc.planes[op.arg], cur, t_lo, best.t, t, u, v)) {
+                if (plane_test<R, true>(sc.planes[op.arg], cur, t_lo, best.t, t, u, v) && hit_takes_over(sc, t, op, best)) {
                     best.t = t;
                     best.pc = pc;
                     best.u = u;

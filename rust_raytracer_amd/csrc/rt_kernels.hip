@@ -897,6 +897,7 @@ int rt_scene_create(const RtSceneDesc* desc, int device, RtScene** out) {
     opt.bvh_on_device = desc && (desc->flags & RT_SCENE_BVH_ON_DEVICE) != 0;
     if (builder && !std::strcmp(builder, "device")) opt.bvh_on_device = true;
     if (builder && !std::strcmp(builder, "host")) opt.bvh_on_device = false;
+    if (const char* e = std::getenv("RT_PRIM_REBUILD")) opt.rebuild_prim_groups = std::atoi(e) != 0;  // A/B, tests
     int n = 0;
     if (opt.bvh_on_device) {  // the device builder needs its device before the scene is compiled
         if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return set_err(RT_E_DEVICE, "no HIP device available");
@@ -1046,18 +1047,23 @@ int rt_scene_info(const RtSceneDesc* desc, uint32_t* flags_out) {
     return RT_OK;
 }
 
-int rt_scene_mesh_stats(const RtSceneDesc* desc, uint64_t out[5]) {
+int rt_scene_mesh_stats(const RtSceneDesc* desc, uint64_t out[8]) {
     using namespace rt;
     if (!desc || !out) return set_err(RT_E_INVALID, "rt_scene_mesh_stats: NULL argument");
     CompiledScene cs;
     std::string err;
-    int st = compile_scene(desc, &cs, &err, CompileOptions());
+    CompileOptions opt;
+    if (const char* e = std::getenv("RT_PRIM_REBUILD")) opt.rebuild_prim_groups = std::atoi(e) != 0;
+    int st = compile_scene(desc, &cs, &err, opt);
     if (st != RT_OK) return set_err(st, err);
     out[0] = cs.tris.size();
     out[1] = cs.nodes.size();
     out[2] = cs.nodes4.size();
     out[3] = cs.max_bvh_depth;
     out[4] = cs.max_bvh4_stack;
+    out[5] = cs.ops.size();
+    out[6] = cs.n_rebuilt_groups;
+    out[7] = cs.n_rebuilt_prims;
     return RT_OK;
 }
 

@@ -33,7 +33,8 @@ enum OpType : int32_t {
 struct Op {
     int32_t type;
     int32_t arg;
-    int32_t skip;   // OP_BOUNDS only
+    int32_t skip;   // OP_BOUNDS / OP_VOL_MID: pc to continue at when culled; every op that can produce a hit: its RANK (>= 1) in the
+                    // reference's depth-first visiting order (ties at equal t go to the lower rank, rt_device.h hit_takes_over)
     int32_t chain;  // index into chain_offsets: transforms enclosing this op, outermost first
 };
 

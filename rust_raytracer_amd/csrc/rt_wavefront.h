@@ -313,13 +313,13 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<
                     case OP_SPHERE: {
                         R t;
                         if (STATS) cnt.prim_tests++;
-                        if (sphere_test(sc.spheres[op.arg], cur, t_lo, best.t, t)) { best.t = t; best.pc = pc; }
+                        if (sphere_test<R, true>(sc.spheres[op.arg], cur, t_lo, best.t, t) && hit_takes_over(sc, t, op, best)) { best.t = t; best.pc = pc; }
                         break;
                     }
                     case OP_PLANE: {
                         R t, u, v;
                         if (STATS) cnt.prim_tests++;
-                        if (plane_test(sc.planes[op.arg], cur, t_lo, best.t, t, u, v)) { best.t = t; best.pc = pc; best.u = u; best.v = v; }
+                        if (plane_test<R, true>(sc.planes[op.arg], cur, t_lo, best.t, t, u, v) && hit_takes_over(sc, t, op, best)) { best.t = t; best.pc = pc; best.u = u; best.v = v; }
                         break;
                     }
                     case OP_SKY:
@@ -460,13 +460,13 @@ RT_DEV bool prims_search(const SceneView<R>& sc, const Ray<R>& wray, int32_t mes
             case OP_SPHERE: {
                 R t;
                 if (STATS) cnt.prim_tests++;
-                if (sphere_test(sc.spheres[op.arg], cur, t_lo, best.t, t)) { best.t = t; best.pc = pc; }
+                if (sphere_test<R, true>(sc.spheres[op.arg], cur, t_lo, best.t, t) && hit_takes_over(sc, t, op, best)) { best.t = t; best.pc = pc; }
                 break;
             }
             case OP_PLANE: {
                 R t, u, v;
                 if (STATS) cnt.prim_tests++;
-                if (plane_test(sc.planes[op.arg], cur, t_lo, best.t, t, u, v)) { best.t = t; best.pc = pc; best.u = u; best.v = v; }
+                if (plane_test<R, true>(sc.planes[op.arg], cur, t_lo, best.t, t, u, v) && hit_takes_over(sc, t, op, best)) { best.t = t; best.pc = pc; best.u = u; best.v = v; }
                 break;
             }
             case OP_MESH:  // deferred (pc == mesh_pc: the only mesh op of this program)

@@ -49,6 +49,9 @@ SCENES = {
     # from behind): the reference's 0 * NaN; 259 of these 2304 pixels are NaN ONLY through a zero-weight prefix
     # (tests/test_zero_weight.py), so a kernel that ends zero-weight paths early fails here
     "zero_weight_nan": ["tests/scenes/zero_weight_nan", "-w=48", "-s=16", "--seed=18"],
+    # 48 spheres + quads in an object BVH, re-built as a SAH tree by the scene compiler (hollow balls with inverted boxes,
+    # coincident duplicates, a list inside the bvh)
+    "sphere_field": ["tests/scenes/sphere_field", "-w=60", "-s=16", "--seed=20"],
 }
 
 
@@ -138,6 +141,35 @@ def test_zero_weight_paths_are_traced_unless_the_light_set_is_safe(dev, monkeypa
         assert s2.stats().rays == ost.rays and rays_fast <= ost.rays
         same = (fast == exact) | (np.isnan(fast) & np.isnan(exact))
         assert same.all()
+
+
+@pytest.mark.parametrize("name", ["sphere_field", "default", "bvh_spheres"])
+def test_rebuilt_primitive_groups_render_the_reference_tree_frame(dev, name, monkeypatch):
+    """SURVEY 8 row f-4 (top-level BVH over primitives): object-BVH / list subtrees of spheres and quads are re-built as
+    SAH trees (rt_compile.cpp).  The frame must be the one the reference's own tree gives, bit for bit (same reachable
+    primitives incl. the inverted-box quirk B-8, first-visited-wins ties by rank), and the oracle's at the f64 bar; the
+    re-built tree must need fewer primitive tests."""
+    hs = api.HostScene(SCENES[name])
+    frames, tests = {}, {}
+    for rebuild in ("0", "1"):
+        monkeypatch.setenv("RT_PRIM_REBUILD", rebuild)
+        groups = api.scene_mesh_stats(hs.desc)["rebuilt_groups"]
+        assert groups == (0 if rebuild == "0" or name == "bvh_spheres" else 1)      # bvh_spheres: 10 spheres, below the threshold
+        scene = api.DeviceScene(hs.desc, 0)
+        for pipe in (api.RT_PIPELINE_WAVEFRONT, api.RT_PIPELINE_MEGAKERNEL):
+            p = hs.params.copy()
+            p.pipeline = pipe
+            p.collect_stats = 1
+            frames[(rebuild, pipe)] = scene.render(hs.camera, p)
+            tests[(rebuild, pipe)] = scene.stats().prim_tests
+    first = frames[("0", api.RT_PIPELINE_WAVEFRONT)]
+    for key, f in frames.items():
+        same = (f == first) | (np.isnan(f) & np.isnan(first))
+        assert same.all(), f"{key}: {int((~same).any(axis=2).sum())} pixels differ from the reference-tree frame"
+    ref, _ = pyoracle.render(hs.desc, hs.camera, hs.params)
+    assert_f64_parity(first, ref)
+    if name != "bvh_spheres":
+        assert tests[("1", api.RT_PIPELINE_WAVEFRONT)] < 0.9 * tests[("0", api.RT_PIPELINE_WAVEFRONT)]   # sphere / quad tests incl. the light pdf re-intersections (box tests are not counted)
 
 
 def test_replica_groups_forced(dev, monkeypatch):
