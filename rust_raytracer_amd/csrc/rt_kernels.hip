@@ -16,6 +16,7 @@
 #include "rt_compile.h"
 #include "rt_device.h"
 #include "rt_wavefront.h"
+#include "rt_mesh32.h"
 
 namespace rt {
 
@@ -314,6 +315,18 @@ struct DeviceScene {
             cast_arr(tris[i].v0, cs.tris[i].v0); cast_arr(tris[i].e1, cs.tris[i].e1); cast_arr(tris[i].e2, cs.tris[i].e2);
             tris[i]._pad = R(0);
         }
+        std::vector<TriRec32> tris32(cs.tris.size());
+        for (size_t i = 0; i < tris32.size(); i++) {
+            const auto& t = cs.tris[i];
+            TriRec32& r = tris32[i];
+            double L = 0.0;
+            for (int a = 0; a < 3; a++) {
+                r.v0[a] = float(t.v0[a]); r.e1[a] = float(t.e1[a]); r.e2[a] = float(t.e2[a]);
+                L = std::fmax(L, std::fmax(std::fabs(t.e1[a]), std::fabs(t.e2[a])));
+            }
+            r.L = round_up<float>(L) * 1.0000002f;  // >= max(|e1|_inf, |e2|_inf)
+            r._p0 = r._p1 = 0.f;
+        }
         std::vector<TriAttr<R>> attrs(cs.attrs.size());
         for (size_t i = 0; i < attrs.size(); i++) {
             const auto& s = cs.attrs[i];
@@ -358,6 +371,7 @@ struct DeviceScene {
         if ((st = buf.upload(nodes4, &view.nodes4)) != RT_OK) return st;
         if ((st = buf.upload(mesh_bounds, &view.mesh_bounds)) != RT_OK) return st;
         if ((st = buf.upload(tris, &view.tris)) != RT_OK) return st;
+        if ((st = buf.upload(tris32, &view.tris32)) != RT_OK) return st;
         if ((st = buf.upload(attrs, &view.attrs)) != RT_OK) return st;
         if ((st = buf.upload(cs.materials, &view.materials)) != RT_OK) return st;
         if ((st = buf.upload(mparams, &view.material_params)) != RT_OK) return st;
@@ -427,6 +441,7 @@ struct RtScene {
         void* pool_dev = nullptr;      // the same descriptor in device memory (k_wf_shade re-reads the array bases from it)
         uint32_t* queue[2] = {nullptr, nullptr};
         uint32_t* mesh_queue = nullptr;
+        uint32_t* fallback_queue = nullptr; // paths k_wf_mesh32 hands back to k_wf_mesh (candidate list full)
         void* mesh_spill = nullptr;        // k_wf_mesh: stack levels beyond the LDS part
         size_t mesh_spill_bytes = 0;
         rt::WfCounters* d_ctr = nullptr;
@@ -545,6 +560,8 @@ static void wf_release_pool(RtScene::Wavefront& w) {
     }
     if (w.mesh_queue) (void)hipFree(w.mesh_queue);
     w.mesh_queue = nullptr;
+    if (w.fallback_queue) (void)hipFree(w.fallback_queue);
+    w.fallback_queue = nullptr;
 }
 
 template <typename R>
@@ -570,6 +587,10 @@ int wf_ensure(RtScene* s, uint32_t capacity) {
         if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->depth))) return st;
         if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->hpc))) return st;
         if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->htri))) return st;
+        if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->cn))) return st;
+        if (int st = alloc(size_t(capacity) * 4 * kMeshCandCap, reinterpret_cast<void**>(&pool->ctri))) return st;
+        pool->cand_stride = capacity;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.fallback_queue), size_t(capacity) * 4));
         for (int q = 0; q < 2; q++) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.queue[q]), size_t(capacity) * 4));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.mesh_queue), size_t(capacity) * 4));
         HIP_TRY(hipMalloc(&w.pool_dev, sizeof(WfPool<R>)));
@@ -672,8 +693,23 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
         blocks_per_cu = std::min<int>(blocks_per_cu, int(env_u32("RT_WF_MESH_BLOCKS", 64)));  // experiments: occupancy scaling
     }
     const uint32_t isect_blocks = uint32_t(n_cu) * uint32_t(blocks_per_cu);
+    // two-stage mesh search (rt_mesh32.h): conservative f32 traversal + exact tests on the candidates; meshes that hit
+    // back faces keep the one-stage kernel
+    bool mesh32 = split && env_u32("RT_WF_MESH32", 0) != 0;  // measured slower than the one-stage kernel (profiles/r02/ab/two_stage_mesh32.txt): off by default
+    if (mesh32 && (s->compiled.meshes[size_t(s->compiled.ops[size_t(mesh_pc)].arg)].flags & RT_MESH_HIT_BACK_FACES)) mesh32 = false;
+    const int lds_levels32 = std::min<int>(mesh_levels, int(env_u32("RT_WF_LDS_LEVELS32", 12)));
+    const size_t lds_mesh32 = size_t(lds_levels32) * 256 * sizeof(uint2) + 4 * kMesh32WaveLds;
+    uint32_t mesh32_blocks = isect_blocks;
+    if (mesh32) {
+        int b32 = 0;
+        if (stats) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b32, k_wf_mesh32<R, true>, 256, lds_mesh32));
+        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b32, k_wf_mesh32<R, false>, 256, lds_mesh32));
+        if (b32 < 1) b32 = 1;
+        b32 = std::min<int>(b32, int(env_u32("RT_WF_MESH32_BLOCKS", 64)));
+        mesh32_blocks = uint32_t(n_cu) * uint32_t(b32);
+    }
     if (split) {
-        size_t need = size_t(std::max(mesh_levels - lds_levels, 1)) * isect_blocks * 256 * sizeof(uint2);
+        size_t need = size_t(std::max(mesh_levels - std::min(lds_levels, lds_levels32), 1)) * std::max(isect_blocks, mesh32_blocks) * 256 * sizeof(uint2);
         if (need > w.mesh_spill_bytes) {
             if (w.mesh_spill) (void)hipFree(w.mesh_spill);
             w.mesh_spill = nullptr;
@@ -714,6 +750,8 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
         init.cursor = 0;
         init.n_mesh = 0;
         init.n_mesh_next = 0;
+        init.n_fallback = 0;
+        init.cursor_fb = 0;
         init.next_sample = first;
         *w.h_ctr = init;
         HIP_TRY(hipMemcpyAsync(w.d_ctr, w.h_ctr, sizeof(WfCounters), hipMemcpyHostToDevice, stream));
@@ -739,10 +777,21 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
                     if (!fuse) RT_LAUNCH_PRIMS_ANY();
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
                     if (prims_only) { /* nothing deferred: the primitive program is the whole closest-hit search */ }
-                    else if (stats)
-                        hipLaunchKernelGGL((k_wf_mesh<R, true>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels);
+                    else if (mesh32) {
+                        const dim3 chunks((upper + WF_CHUNK - 1) / WF_CHUNK);
+                        if (stats) {
+                            hipLaunchKernelGGL((k_wf_mesh32<R, true>), dim3(mesh32_blocks), dim3(256), lds_mesh32, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels32);
+                            hipLaunchKernelGGL((k_wf_mesh_exact<R, true>), chunks, dim3(256), 0, stream, ds.view, pool, w.mesh_queue, w.fallback_queue, w.d_ctr, s->d_counters, mesh_pc);
+                            hipLaunchKernelGGL((k_wf_mesh<R, true>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, w.fallback_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels, &w.d_ctr->n_fallback, &w.d_ctr->cursor_fb);
+                        } else {
+                            hipLaunchKernelGGL((k_wf_mesh32<R, false>), dim3(mesh32_blocks), dim3(256), lds_mesh32, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels32);
+                            hipLaunchKernelGGL((k_wf_mesh_exact<R, false>), chunks, dim3(256), 0, stream, ds.view, pool, w.mesh_queue, w.fallback_queue, w.d_ctr, s->d_counters, mesh_pc);
+                            hipLaunchKernelGGL((k_wf_mesh<R, false>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, w.fallback_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels, &w.d_ctr->n_fallback, &w.d_ctr->cursor_fb);
+                        }
+                    } else if (stats)
+                        hipLaunchKernelGGL((k_wf_mesh<R, true>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels, &w.d_ctr->n_mesh, &w.d_ctr->cursor);
                     else
-                        hipLaunchKernelGGL((k_wf_mesh<R, false>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels);
+                        hipLaunchKernelGGL((k_wf_mesh<R, false>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels, &w.d_ctr->n_mesh, &w.d_ctr->cursor);
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 } else {
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));

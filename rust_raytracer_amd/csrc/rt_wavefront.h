@@ -40,6 +40,11 @@ struct WfPool {
     uint32_t* depth;                 // remaining depth (the `depth` argument of ray_color)
     R *ht, *hu, *hv;                 // closest hit: t, (u, v)
     int32_t *hpc, *htri;             // op that produced it (-1 none), triangle slot
+    // two-stage mesh search (rt_mesh32.h): per path the number of candidate triangles (kMeshCandOverflow: list full) and
+    // the candidates themselves, candidate k of slot s at ctri[k * cand_stride + s]
+    uint32_t* cn;
+    uint32_t* ctri;
+    size_t cand_stride;
 };
 
 // Element `slot` of a pool array through a 32-bit BYTE offset.  `base + zext(offset)` lets the compiler address every
@@ -56,6 +61,8 @@ struct WfCounters {
     uint32_t cursor;      // next queue entry to hand out (persistent intersect / mesh kernel)
     uint32_t n_mesh;      // entries of the mesh queue (paths whose ray enters the deferred mesh's box)
     uint32_t n_mesh_next; // mesh queue being filled by the fused shade kernel for the NEXT iteration (k_wf_advance moves it to n_mesh)
+    uint32_t n_fallback;  // paths whose candidate list overflowed in k_wf_mesh32: re-done by k_wf_mesh
+    uint32_t cursor_fb;   // ... and the cursor of that run
     uint32_t _pad;
     unsigned long long next_sample;  // next sample (within the group) to start
 };
@@ -592,7 +599,9 @@ template <typename R, bool STATS>
 __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc, WfPool<R> pool, const uint32_t* __restrict__ mesh_queue,
                                                                  WfCounters* __restrict__ ctr, DeviceCounters* counters,
                                                                  uint32_t refill_min, uint32_t inner_min, int32_t mesh_pc,
-                                                                 uint2* __restrict__ spill, int lds_levels) {
+                                                                 uint2* __restrict__ spill, int lds_levels,
+                                                                 const uint32_t* __restrict__ n_ptr, uint32_t* __restrict__ cursor_ptr) {
+    // n_ptr / cursor_ptr: length and hand-out cursor of `mesh_queue` (&ctr->n_mesh / &ctr->cursor, or the fallback queue's)
     extern __shared__ uint2 lds_stack2[];
     MeshStack stk;
     stk.lds = lds_stack2 + threadIdx.x;
@@ -606,7 +615,7 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
     stk.spill = spill + (size_t(blockIdx.x) * blockDim.x + threadIdx.x);
     stk.lds_levels = lds_levels;
     stk.spill_stride = gridDim.x * blockDim.x;
-    const uint32_t n = ctr->n_mesh;
+    const uint32_t n = *n_ptr;
     const R t_lo = R(0.001);
     const Op mop = sc.ops[mesh_pc];
     const MeshInst mi = sc.meshes[mop.arg];
@@ -661,7 +670,7 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
         if (!exhausted && n_idle >= refill_min) {
             uint32_t my = 0;
             if (STATS) w_refill++;
-            if (wave_fetch(range, idle, &ctr->cursor, n, exhausted, my)) {
+            if (wave_fetch(range, idle, cursor_ptr, n, exhausted, my)) {
                 if (STATS) l_refill++;
                 slot = mesh_queue[my];
                 Ray<R> wray = make_ray(mk<R>(at(pool.ox, slot), at(pool.oy, slot), at(pool.oz, slot)), mk<R>(at(pool.dx, slot), at(pool.dy, slot), at(pool.dz, slot)));
@@ -1014,6 +1023,8 @@ __global__ void k_wf_advance(WfCounters* ctr) {
     ctr->cursor = 0;
     ctr->n_mesh = ctr->n_mesh_next;  // filled by k_wf_shade<FUSE> (0 otherwise)
     ctr->n_mesh_next = 0;
+    ctr->n_fallback = 0;
+    ctr->cursor_fb = 0;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -240,14 +240,15 @@ def test_every_kernel_variant_is_bit_identical(dev, name, monkeypatch):
     p.pipeline = api.RT_PIPELINE_WAVEFRONT
     for stats in (0, 1):
         for lds in ("1", "0"):
-            for split, fuse in (("1", "0"), ("1", "1"), ("0", "0")):
+            for split, fuse, mesh32 in (("1", "0", "0"), ("1", "1", "0"), ("1", "0", "1"), ("0", "0", "0")):
                 monkeypatch.setenv("RT_LDS_TABLES", lds)
                 monkeypatch.setenv("RT_WF_SPLIT", split)
                 monkeypatch.setenv("RT_WF_FUSE", fuse)    # primitive program inside k_wf_shade instead of a separate pass
+                monkeypatch.setenv("RT_WF_MESH32", mesh32)  # two-stage mesh search: conservative f32 traversal + exact tests on the candidates
                 p.collect_stats = stats
                 wf = scene.render(hs.camera, p)
                 same = (wf == mega) | (np.isnan(wf) & np.isnan(mega))
-                assert same.all(), f"variant stats={stats} lds={lds} split={split} fuse={fuse}: {int((~same).any(axis=2).sum())} pixels differ"
+                assert same.all(), f"variant stats={stats} lds={lds} split={split} fuse={fuse} mesh32={mesh32}: {int((~same).any(axis=2).sum())} pixels differ"
 
 
 def test_stats_counters_and_collect_flag(dev):
