@@ -5,7 +5,7 @@
 //
 // New, optional flags (ignored by the reference's parser, so command lines stay compatible):
 //   --seed=<u64>  --gpus=<n>  --precision=f64|f32  --pipeline=auto|mega|wavefront  --bvh=host|device
-// With --gpus=n the frame is row-tiled in interleaved 16-row bands, one host thread per GPU;
+// With --gpus=n the frame is row-tiled in interleaved bands (16 rows, or finer when that balances the GPUs), one host thread per GPU;
 // the tiles are assembled on the host here (bench.py shows the RCCL gather path used for the
 // multi-process launch).
 #include <chrono>
@@ -53,6 +53,20 @@ int main(int argc, char** argv) {
     }
     if (int(gpus) > available) gpus = uint32_t(available);
     const uint32_t W = cam->image_width, H = cam->image_height;
+    // interleaved row bands: 16 rows unless a finer band gives the most loaded GPU fewer rows (it sets the time of the frame)
+    uint32_t band = 16;
+    if (gpus > 1) {
+        uint32_t best_rows = 0xFFFFFFFFu;
+        for (uint32_t b : {16u, 8u, 4u, 2u, 1u}) {
+            uint32_t most = 0;
+            for (uint32_t g = 0; g < gpus; g++) {
+                uint32_t rows = 0;
+                for (uint32_t y = 0; y < H; y++) rows += ((y / b) % gpus == g);
+                most = rows > most ? rows : most;
+            }
+            if (most < best_rows) { best_rows = most; band = b; }
+        }
+    }
     std::vector<double> frame(size_t(W) * H * 4, 0.0);  // camera.create_buffer(), main.rs:74
     std::vector<std::string> errors(gpus);
     std::vector<std::thread> workers;
@@ -66,7 +80,7 @@ int main(int argc, char** argv) {
             }
             RtRenderParams p = *params;
             if (gpus > 1) {
-                p.band_rows = 16;
+                p.band_rows = band;
                 p.n_parts = gpus;
                 p.part = g;
             }
@@ -77,7 +91,7 @@ int main(int argc, char** argv) {
             if (!errors[g].empty()) return;
             uint32_t r = 0;
             for (uint32_t y = 0; y < H; y++) {
-                bool mine = gpus == 1 || (y / 16) % gpus == g;
+                bool mine = gpus == 1 || (y / band) % gpus == g;
                 if (!mine) continue;
                 std::memcpy(&frame[size_t(y) * W * 4], &part[size_t(r) * W * 4], size_t(W) * 4 * sizeof(double));
                 r++;

@@ -587,10 +587,9 @@ int wf_ensure(RtScene* s, uint32_t capacity) {
         if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->depth))) return st;
         if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->hpc))) return st;
         if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->htri))) return st;
-        if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->cn))) return st;
-        if (int st = alloc(size_t(capacity) * 4 * kMeshCandCap, reinterpret_cast<void**>(&pool->ctri))) return st;
+        pool->cn = nullptr;   // candidate lists of the two-stage mesh search: allocated on first use (wf_ensure_candidates)
+        pool->ctri = nullptr;
         pool->cand_stride = capacity;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.fallback_queue), size_t(capacity) * 4));
         for (int q = 0; q < 2; q++) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.queue[q]), size_t(capacity) * 4));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.mesh_queue), size_t(capacity) * 4));
         HIP_TRY(hipMalloc(&w.pool_dev, sizeof(WfPool<R>)));
@@ -613,6 +612,26 @@ int wf_ensure(RtScene* s, uint32_t capacity) {
     return RT_OK;
 }
 
+// Buffers of the two-stage mesh search (rt_mesh32.h), only when that variant is selected: 28 B per pool slot.
+template <typename R>
+int wf_ensure_candidates(RtScene* s) {
+    RtScene::Wavefront& w = s->wf;
+    auto* pool = static_cast<WfPool<R>*>(w.pool_view);
+    if (pool->cn) return RT_OK;
+    const size_t capacity = w.capacity;
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, capacity * 4));
+    w.allocs.push_back(p);
+    pool->cn = static_cast<uint32_t*>(p);
+    HIP_TRY(hipMalloc(&p, capacity * 4 * kMeshCandCap));
+    w.allocs.push_back(p);
+    pool->ctri = static_cast<uint32_t*>(p);
+    pool->cand_stride = capacity;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.fallback_queue), capacity * 4));
+    HIP_TRY(hipMemcpy(w.pool_dev, pool, sizeof(WfPool<R>), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
 template <typename R>
 int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, const RtRenderParams& p, uint32_t owned,
                      double* d_out, hipStream_t stream) {
@@ -623,16 +642,26 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     const uint32_t T = p.thread_count;
     const uint64_t per_replica = uint64_t(strata) * npix;
     // pool size: enough paths to keep every CU busy for several rounds per launch
-    // 64M paths (9.6 GB of f64 state).  Measured at full size, round 2 (k_wf_mesh ms per step / Msamples/s): 16M 789 / 1067,
-    // 32M 731 / 1115, 64M 699 / 1144, 128M 686 / 1153, 256M 682 / 1128: every launch of the persistent mesh kernel ends with
-    // a drain of ~0.4 ms (the longest remaining traversals, dependent fetches), so fewer, larger launches win until the pool's
-    // own streams get slower.
-    uint32_t capacity = env_u32("RT_WF_POOL", 1u << 26);
+    // Pool size.  Every launch of the persistent mesh kernel ends with a drain of ~0.4 ms (the longest remaining traversals:
+    // dependent fetches), so fewer, larger launches win — measured at full size (1.44 G samples), k_wf_mesh ms per step /
+    // Msamples/s: 16M 789 / 1067, 32M 731 / 1115, 64M 699 / 1144, 128M 686 / 1153, 256M 682 / 1128 — but the pool also is what
+    // drains at the end of a render (its paths die out over ~20 ever smaller iterations), which costs in proportion to its
+    // size: for one rank's share of an 8-way partition (180 M samples) 64M / 32M / 16M / 8M slots take 204 / 181 / 187 / 200 ms.
+    // launches ~ samples / pool and tail ~ pool: the best size grows with the square root of the work, 64M at 1.44 G samples.
+    uint32_t capacity;
+    {
+        const double total_samples = double(per_replica) * double(T);
+        double c = 67108864.0 * std::sqrt(total_samples / 1.44e9);
+        c = std::fmin(std::fmax(c, 1048576.0), 134217728.0);
+        capacity = env_u32("RT_WF_POOL", uint32_t(c) & ~0xFFFFFu);
+    }
     if (capacity > (1u << 28)) capacity = 1u << 28;  // the kernels address pool arrays through 32-bit byte offsets (rt_wavefront.h, at())
     if (uint64_t(capacity) > per_replica * T) capacity = uint32_t(per_replica * T);
     if (capacity < 64) capacity = 64;
     if (int st = wf_ensure<R>(s, capacity)) return st;
     RtScene::Wavefront& w = s->wf;
+    if (env_u32("RT_WF_MESH32", 0) != 0)
+        if (int st = wf_ensure_candidates<R>(s)) return st;
     WfPool<R> pool = *static_cast<WfPool<R>*>(w.pool_view);
 
     // per-sample radiance buffer: as many replicas per group as the memory budget allows
@@ -695,7 +724,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     const uint32_t isect_blocks = uint32_t(n_cu) * uint32_t(blocks_per_cu);
     // two-stage mesh search (rt_mesh32.h): conservative f32 traversal + exact tests on the candidates; meshes that hit
     // back faces keep the one-stage kernel
-    bool mesh32 = split && env_u32("RT_WF_MESH32", 0) != 0;  // measured slower than the one-stage kernel (profiles/r02/ab/two_stage_mesh32.txt): off by default
+    bool mesh32 = split && pool.cn != nullptr && env_u32("RT_WF_MESH32", 0) != 0;  // measured slower than the one-stage kernel (profiles/r02/ab/two_stage_mesh32.txt): off by default
     if (mesh32 && (s->compiled.meshes[size_t(s->compiled.ops[size_t(mesh_pc)].arg)].flags & RT_MESH_HIT_BACK_FACES)) mesh32 = false;
     const int lds_levels32 = std::min<int>(mesh_levels, int(env_u32("RT_WF_LDS_LEVELS32", 12)));
     const size_t lds_mesh32 = size_t(lds_levels32) * 256 * sizeof(uint2) + 4 * kMesh32WaveLds;

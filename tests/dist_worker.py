@@ -22,7 +22,7 @@ def main():
     hs = api.HostScene(["tests/scenes/single_light", "-w=40", "-r=0.5", "-s=4", "--seed=21"])   # 40 x 80: 5 bands of 16 rows
 
     def render_rows(p):
-        assert (p.n_parts, p.part, p.band_rows) == (world, rank, rtdist.BAND_ROWS)
+        assert (p.n_parts, p.part, p.band_rows) == (world, rank, rtdist.band_rows_for(hs.height, world))
         img, _ = pyoracle.render(hs.desc, hs.camera, p)
         assert img.shape[0] == len(rtdist.rows_of_part(hs.height, world, rank))
         return torch.from_numpy(img)

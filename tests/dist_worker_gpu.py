@@ -30,7 +30,7 @@ def main():
     dev = torch.device("cuda", local)
 
     def render_rows(p):
-        assert (p.n_parts, p.part, p.band_rows) == (world, rank, rtdist.BAND_ROWS)
+        assert (p.n_parts, p.part, p.band_rows) == (world, rank, rtdist.band_rows_for(hs.height, world))
         rows = len(rtdist.rows_of_part(hs.height, world, rank))
         out = torch.empty((rows, hs.width, 4), dtype=torch.float64, device=dev)
         scene.render_device(hs.camera, p, out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)

@@ -8,6 +8,7 @@ import sys
 
 import pytest
 
+from rust_raytracer_amd import api
 from rust_raytracer_amd import dist as rtdist
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,9 +29,18 @@ def test_partition_is_a_partition():
             flat = sorted(y for part in rows for y in part)
             assert flat == list(range(h))
             assert rtdist.max_rows(h, n) == max(len(r) for r in rows)
-    # 1200 rows over 8 GPUs: 75 bands -> parts of 160 or 144 rows (balanced within one band)
-    sizes = [len(rtdist.rows_of_part(1200, 8, r)) for r in range(8)]
-    assert max(sizes) - min(sizes) <= rtdist.BAND_ROWS and sum(sizes) == 1200
+    # 1200 rows over 8 GPUs: 16-row bands would give 160 or 144 rows per rank; the band height is chosen so that the most
+    # loaded rank (it sets the time of the run) has as few rows as possible: 2-row bands, 150 rows each
+    assert rtdist.band_rows_for(1200, 8) == 2
+    assert [len(rtdist.rows_of_part(1200, 8, r)) for r in range(8)] == [150] * 8
+    assert rtdist.band_rows_for(2400, 8) == 4 and rtdist.band_rows_for(1200, 2) == 8 and rtdist.band_rows_for(1200, 3) == 16
+    for h in (1, 15, 16, 17, 80, 266, 800, 1200, 2400):
+        for n in (2, 3, 4, 8):
+            b = rtdist.band_rows_for(h, n)
+            most = max(len(rtdist.rows_of_part(h, n, r)) for r in range(n))
+            assert all(most <= max(len(rtdist.rows_of_part(h, n, r, bb)) for r in range(n)) for bb in (16, 8, 4, 2, 1)), (h, n, b)
+            p = rtdist.partition_params(api.RtRenderParams(), n, 0, h)
+            assert p.band_rows == b and sorted(y for r in range(n) for y in rtdist.rows_of_part(h, n, r)) == list(range(h))
 
 
 @pytest.mark.parametrize("world", [2, 3])

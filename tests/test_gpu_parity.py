@@ -394,29 +394,30 @@ def test_headline_config_rows_match_oracle(dev):
 
 def test_c5_config_rows_of_one_rank_match_oracle(dev):
     """BASELINE.json's multi-GPU configuration C5 (cornell_dragon, 2400x2400, 4000 spp = 10 replicas x 20x20 strata,
-    frame row-tiled in 16-row bands over 8 GPUs), the share of rank 3.  (1) Two full rows of that share (1075 and
-    2227, bands 67 and 139: both 3 mod 8) against the oracle at the f64 bar.  (2) The rank's whole share exactly as
-    bench.py --gpus 8 renders it (band_rows 16, 8 parts, part 3: 304 rows, 2.9 G samples): its per-sample buffer
-    (70 GB) is over the 64 GB budget, so this is the replica-group path on the real configuration; the two rows cut
-    out of it must be the same bits."""
+    frame row-tiled over 8 GPUs), the share of rank 3 exactly as `bench.py --gpus 8` partitions it
+    (dist.partition_params: 4-row bands, 300 rows per rank).  (1) Two full rows of that share (1070 and 2222) against
+    the oracle at the f64 bar.  (2) The rank's whole share (2.9 G samples): its per-sample buffer (69 GB) is over the
+    64 GB budget, so this is the replica-group path on the real configuration; the two rows cut out of it must be the
+    same bits."""
+    from rust_raytracer_amd import dist as rtdist
     ensure_dragon()
     hs = api.HostScene(["scenes/cornell_dragon", "-w=2400", "-s=4000", "-t=10", "--seed=1"])
     assert (hs.width, hs.height, hs.spp) == (2400, 2400, 4000) and hs.params.sqrt_spt == 20 and hs.params.thread_count == 10
     scene = api.DeviceScene(hs.desc, 0)
-    q = hs.params.copy()
-    q.band_rows, q.n_parts, q.part = 1, 1152, 1075
-    rows = api.owned_rows(hs.height, q)
-    assert list(rows) == [1075, 2227]
-    share = hs.params.copy()
-    share.band_rows, share.n_parts, share.part = 16, 8, 3
+    share = rtdist.partition_params(hs.params, 8, 3, hs.height)
+    assert (share.band_rows, share.n_parts, share.part) == (4, 8, 3)
     share_rows = api.owned_rows(hs.height, share)
-    assert len(share_rows) == 304 and all(r in share_rows for r in rows)
+    assert len(share_rows) == 300 and share_rows == rtdist.rows_of_part(hs.height, 8, 3)
+    q = hs.params.copy()
+    q.band_rows, q.n_parts, q.part = 1, 1152, 1070
+    rows = api.owned_rows(hs.height, q)
+    assert list(rows) == [1070, 2222] and all(r in share_rows for r in rows)
     gpu = scene.render(hs.camera, q)
     ref, st = pyoracle.render(hs.desc, hs.camera, q)
     assert st.samples == 2 * 2400 * 4000
     assert_f64_parity(gpu, ref)
     full = scene.render(hs.camera, share)
-    assert full.shape == (304, 2400, 4)
+    assert full.shape == (300, 2400, 4)
     assert scene.stats().n_replica_groups >= 2
     np.testing.assert_array_equal(full[[share_rows.index(r) for r in rows]], gpu)
 

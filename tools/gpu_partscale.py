@@ -14,7 +14,7 @@ dev = torch.device("cuda", 0)
 def run(n, pool):
     if pool: os.environ["RT_WF_POOL"] = str(pool)
     else: os.environ.pop("RT_WF_POOL", None)
-    p = rtdist.partition_params(hs.params, n, 0)
+    p = rtdist.partition_params(hs.params, n, 0, hs.height)
     rows = len(rtdist.rows_of_part(hs.height, n, 0))
     out = torch.empty((rows, hs.width, 4), dtype=torch.float64, device=dev)
     st = torch.cuda.current_stream(dev)
@@ -26,7 +26,7 @@ def run(n, pool):
     return time.perf_counter() - t0
 base = None
 for n in (1, 2, 4, 8):
-    for pool in (0, 1 << 25, 1 << 24, 1 << 23):
+    for pool in (0, 1 << 26, 1 << 25, 1 << 24):
         if n == 1 and pool: continue
         t = run(n, pool)
         if n == 1: base = t

@@ -1,2 +1,6 @@
 #!/bin/bash
-bash tools/gpu_sweep.sh RT_DEVICE_LIB $PWD/rust_raytracer_amd/librt_mi355.so $PWD/tools/variants_extraloads.so
+source tools/gpu_steps.sh
+step r2_tests10 900 python -m pytest tests -m gpu -q
+tail -5 gpurun_out/r2_tests10.log
+step partscale_r2b 600 python tools/gpu_partscale.py
+grep -v amdgpu gpurun_out/partscale_r2b.log
