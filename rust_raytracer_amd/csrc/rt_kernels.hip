@@ -752,6 +752,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     // small tables staged in LDS by the prims / shade kernels when they fit
     const bool lds_tables = ds.view.lay.total_bytes <= 48u * 1024u && env_u32("RT_LDS_TABLES", 1) != 0;
     const size_t lds_small = lds_tables ? size_t(ds.view.lay.total_bytes) : 0;
+    const bool iter_log = env_u32("RT_WF_ITER_LOG", 0) != 0;
     const bool trace_pool = env_u32("RT_WF_TRACE", 0) != 0;  // debug: dump the first pool slots after every iteration
     const uint32_t check_every = trace_pool ? 1u : std::min<uint32_t>(32u, std::max<uint32_t>(1u, env_u32("RT_WF_CHECK", 8)));  // 4 timing events per iteration, 128 events
     const bool tex = s->compiled.needs_tex_interpreter;
@@ -852,12 +853,17 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
                 phase_ms[0] += ms;
             }
             first_round = false;
-            for (size_t e = ev0; e + 3 < ev; e += 4)
+            for (size_t e = ev0; e + 3 < ev; e += 4) {
+                float it_ms[3];
                 for (int ph = 0; ph < 3; ph++) {
-                    float ms = 0.f;
-                    HIP_TRY(hipEventElapsedTime(&ms, w.events[e + ph], w.events[e + ph + 1]));
-                    phase_ms[ph] += ms;
+                    it_ms[ph] = 0.f;
+                    HIP_TRY(hipEventElapsedTime(&it_ms[ph], w.events[e + ph], w.events[e + ph + 1]));
+                    phase_ms[ph] += it_ms[ph];
                 }
+                if (iter_log)  // RT_WF_ITER_LOG=1 (with RT_WF_CHECK=1 the queue length printed is the one of this very iteration)
+                    std::fprintf(stderr, "[wf iter] group %u: <= %u paths queued: prims %.3f ms, traversal %.3f ms, shade %.3f ms\n", n_groups, upper,
+                                 it_ms[0], it_ms[1], it_ms[2]);
+            }
             if (trace_pool) {
                 const uint32_t n = std::min<uint32_t>(first, env_u32("RT_WF_TRACE", 0));
                 std::vector<R> a[12];
