@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RT_MI355_ABI_VERSION 1
+#define RT_MI355_ABI_VERSION 2  /* 2: RtRenderStats grew (per-kernel times, state bytes, iterations, replica groups) */
 
 typedef enum RtStatus {
     RT_OK = 0,

@@ -1,7 +1,7 @@
 #!/bin/bash
 source tools/gpu_steps.sh
-step r2_tests11 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x
-tail -5 gpurun_out/r2_tests11.log
-bash tools/gpu_sweep.sh RT_WF_DRAIN 0 4 8 16 32 64
-python tools/gpu_tail_probe.py 2>&1 | tail -1
-RT_WF_DRAIN=0 python tools/gpu_tail_probe.py 2>&1 | tail -1
+step final_tests 1000 python -m pytest tests -m gpu -q
+tail -4 gpurun_out/final_tests.log
+step final_smoke 300 python -c "import __graft_entry__ as g; g.smoke()"
+tail -2 gpurun_out/final_smoke.log
+bash tools/profile.sh r02_c4_f64_final
