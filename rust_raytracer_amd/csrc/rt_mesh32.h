@@ -55,13 +55,6 @@ constexpr uint32_t kMeshCandCap = 6;            // candidates kept per path; mor
 constexpr uint32_t kMeshCandOverflow = 0xFFFFFFFFu;
 constexpr uint32_t kMesh32WaveLds = 1024u + 64u * 4u;  // per wave: pair table (512 x u16) + one float result per lane
 
-// f32 at most x (x finite): round to nearest, then subtract a relative margin.
-RT_DEV float f32_at_most(double x) {
-    float f = float(x);
-    return f - fabsf(f) * 9.5367431640625e-7f - 1e-30f;
-}
-RT_DEV float f32_at_most(float x) { return x - fabsf(x) * 9.5367431640625e-7f - 1e-30f; }
-
 template <typename R, bool STATS>
 __global__ void __launch_bounds__(256, RT_MESH32_WAVES) k_wf_mesh32(SceneView<R> sc, WfPool<R> pool, const uint32_t* __restrict__ mesh_queue,
                                                                      WfCounters* __restrict__ ctr, DeviceCounters* counters,
