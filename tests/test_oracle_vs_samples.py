@@ -77,3 +77,27 @@ def test_default_scene_sky_matches_sample0():
     np.testing.assert_allclose(ours, ref, atol=1.5)
     expect = api.tonemap_rgb8(np.array([[[0.2, 0.6, 2.0, 0.0]]]))[0, 0]
     np.testing.assert_allclose(ref, expect, atol=1.5)
+
+
+def test_default_scene_metal_monkey_matches_sample0():
+    """sample0.png again: the Suzanne mesh (Metal 0.8,0.6,0.2, roughness 0.05, inside a Transform) under sun + sky is at a fixed
+    place; what it mirrors — the 440-sphere field — is drawn from the reference's entropy-seeded generator, so the comparison
+    is a regional mean over several of OUR seeds: the monkey's blocks agree with the real Rust render to a few percent in
+    linear radiance (measured per seed: 0.93 .. 1.06), the whole invertible image to ~10 % (sphere colours and count differ
+    from draw to draw).  A statistical pin of Metal::scatter on mesh normals, Transform, Sun / Sky sampling with the light
+    bias and the depth-of-field camera (f/2.8) against the reference itself."""
+    ref = GOLD["sample0_linear_mean"].astype(np.float64)
+    ok = GOLD["sample0_clipped_frac"] < 0.02
+    monkey = (slice(30, 60), slice(55, 95))
+    ratios, global_ratios = [], []
+    for seed in (1, 2, 3):
+        hs = api.HostScene(["-w=150", "-s=64", "-t=4", f"--seed={seed}"])
+        assert (hs.width, hs.height) == (150, 100)
+        img, _ = pyoracle.render(hs.desc, hs.camera, hs.params)
+        lin = img[..., :3]
+        m = ok[monkey]
+        assert m.mean() > 0.8
+        ratios.append(lin[monkey][m].mean(axis=0) / ref[monkey][m].mean(axis=0))
+        global_ratios.append(lin[ok].mean(axis=0) / ref[ok].mean(axis=0))
+    np.testing.assert_allclose(np.mean(ratios, axis=0), 1.0, atol=0.08)
+    np.testing.assert_allclose(np.mean(global_ratios, axis=0), 1.0, atol=0.15)
