@@ -441,9 +441,8 @@ template <typename R, bool STATS>
 RT_DEV bool prims_search(const SceneView<R>& sc, const Ray<R>& wray, int32_t mesh_pc, Best<R>& best, LaneCounters& cnt) {
     const R t_lo = R(0.001);
     Ray<R> cur = wray;
-    Ray<R> mesh_ray = wray;
     best.t = Lim<R>::inf(); best.pc = -1; best.tri = -1; best.u = R(0); best.v = R(0);
-    bool mesh_reached = false;
+    bool to_mesh = false;
     int32_t pc = 0;
     if (STATS) cnt.rays++;
     for (;;) {
@@ -476,10 +475,26 @@ RT_DEV bool prims_search(const SceneView<R>& sc, const Ray<R>& wray, int32_t mes
                 if (plane_test<R, true>(sc.planes[op.arg], cur, t_lo, best.t, t, u, v) && hit_takes_over(sc, t, op, best)) { best.t = t; best.pc = pc; best.u = u; best.v = v; }
                 break;
             }
-            case OP_MESH:  // deferred (pc == mesh_pc: the only mesh op of this program)
-                mesh_reached = true;
-                mesh_ray = cur;
+            case OP_MESH: {  // deferred (pc == mesh_pc: the only mesh op of this program)
+                // Does the ray enter the mesh's box inside (t_lo, best.t]?  Decided HERE, with the closest hit so far (ops behind
+                // the mesh can only shorten the interval, and the test only culls: conservative), so that no copy of the
+                // object-space ray has to stay alive to the end of the program.
+                const Bounds<R>& rb = sc.mesh_bounds[op.arg];
+                const R big = sizeof(R) == 8 ? R(1e150) : R(1e18);
+                V3<R> inv = {fabs(cur.inv.x) > big ? copysign(big, cur.inv.x) : cur.inv.x,
+                             fabs(cur.inv.y) > big ? copysign(big, cur.inv.y) : cur.inv.y,
+                             fabs(cur.inv.z) > big ? copysign(big, cur.inv.z) : cur.inv.z};
+                // a few ulps of slack on the box: this test must never be stricter than the traversal
+                const R eps = Lim<R>::eps() * R(16);
+                R t0x = (rb.lo[0] - fabs(rb.lo[0]) * eps - cur.o.x) * inv.x, t1x = (rb.hi[0] + fabs(rb.hi[0]) * eps - cur.o.x) * inv.x;
+                R t0y = (rb.lo[1] - fabs(rb.lo[1]) * eps - cur.o.y) * inv.y, t1y = (rb.hi[1] + fabs(rb.hi[1]) * eps - cur.o.y) * inv.y;
+                R t0z = (rb.lo[2] - fabs(rb.lo[2]) * eps - cur.o.z) * inv.z, t1z = (rb.hi[2] + fabs(rb.hi[2]) * eps - cur.o.z) * inv.z;
+                R tn = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmax(fmin(t0z, t1z), t_lo));
+                R tf = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmin(fmax(t0z, t1z), best.t));
+                tf = tf + fabs(tf) * eps;
+                to_mesh = (tn <= tf) && rb.lo[0] <= rb.hi[0];
                 break;
+            }
             case OP_SKY:
                 if (STATS) cnt.prim_tests++;
                 if (!(Lim<R>::inf() > best.t)) { best.t = Lim<R>::inf(); best.pc = pc; }
@@ -498,28 +513,16 @@ RT_DEV bool prims_search(const SceneView<R>& sc, const Ray<R>& wray, int32_t mes
         }
         pc++;
     }
-    if (!mesh_reached) return false;
-    // does the ray enter the mesh's box inside (t_lo, best.t]?  (culling only: conservative)
-    const Bounds<R>& rb = sc.mesh_bounds[sc.ops[mesh_pc].arg];
-    const R big = sizeof(R) == 8 ? R(1e150) : R(1e18);
-    V3<R> inv = {fabs(mesh_ray.inv.x) > big ? copysign(big, mesh_ray.inv.x) : mesh_ray.inv.x,
-                 fabs(mesh_ray.inv.y) > big ? copysign(big, mesh_ray.inv.y) : mesh_ray.inv.y,
-                 fabs(mesh_ray.inv.z) > big ? copysign(big, mesh_ray.inv.z) : mesh_ray.inv.z};
-    // a few ulps of slack on the box: this test must never be stricter than the traversal
-    const R eps = Lim<R>::eps() * R(16);
-    R t0x = (rb.lo[0] - fabs(rb.lo[0]) * eps - mesh_ray.o.x) * inv.x, t1x = (rb.hi[0] + fabs(rb.hi[0]) * eps - mesh_ray.o.x) * inv.x;
-    R t0y = (rb.lo[1] - fabs(rb.lo[1]) * eps - mesh_ray.o.y) * inv.y, t1y = (rb.hi[1] + fabs(rb.hi[1]) * eps - mesh_ray.o.y) * inv.y;
-    R t0z = (rb.lo[2] - fabs(rb.lo[2]) * eps - mesh_ray.o.z) * inv.z, t1z = (rb.hi[2] + fabs(rb.hi[2]) * eps - mesh_ray.o.z) * inv.z;
-    R tn = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmax(fmin(t0z, t1z), t_lo));
-    R tf = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmin(fmax(t0z, t1z), best.t));
-    tf = tf + fabs(tf) * eps;
-    return (tn <= tf) && rb.lo[0] <= rb.hi[0];
+    return to_mesh;
 }
 
 // Stand-alone form: only the FIRST iteration of a replica group needs it (the camera rays of k_wf_generate); from
 // then on k_wf_shade<FUSE> runs prims_search on every new ray while it is still in registers.
+#ifndef RT_PRIMS_WAVES
+#define RT_PRIMS_WAVES 5  // 95 VGPRs without scratch since the mesh-box test moved to the mesh op (round 2); 4 waves before: 171 -> 157 ms per step
+#endif
 template <typename R, bool STATS, bool LDS>
-__global__ void __launch_bounds__(256) k_wf_prims(SceneView<R> sc_g, WfPool<R> pool, const uint32_t* __restrict__ queue,
+__global__ void __launch_bounds__(256, RT_PRIMS_WAVES) k_wf_prims(SceneView<R> sc_g, WfPool<R> pool, const uint32_t* __restrict__ queue,
                                                   uint32_t* __restrict__ mesh_queue, WfCounters* __restrict__ ctr,
                                                   DeviceCounters* counters, int32_t mesh_pc) {
     extern __shared__ __align__(16) char lds_raw[];
