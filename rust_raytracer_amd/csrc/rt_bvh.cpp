@@ -185,9 +185,10 @@ struct Cand {
         return dx * dy + dy * dz + dz * dx;
     }
 };
+template <int W>
 struct Collapser {
     const BvhBuild& b2;
-    Bvh4Build out;
+    BvhNBuild<W> out;
     uint32_t build(int32_t n2, uint32_t depth, uint32_t stack_above) {
         uint32_t idx = uint32_t(out.nodes.size());
         out.nodes.emplace_back();
@@ -202,7 +203,7 @@ struct Collapser {
         };
         add_children(n2);
         for (;;) {
-            if (c.size() >= 4) break;
+            if (c.size() >= size_t(W)) break;
             int best = -1;
             double best_area = -1.0;
             for (size_t i = 0; i < c.size(); i++)
@@ -215,8 +216,8 @@ struct Collapser {
         uint32_t n_children = uint32_t(c.size());
         uint32_t stack_here = stack_above + (n_children > 0 ? n_children - 1 : 0);
         if (stack_here + 1 > out.max_stack) out.max_stack = stack_here + 1;
-        BuildNode4 node{};
-        for (int k = 0; k < 4; k++) {
+        BuildNodeN<W> node{};
+        for (int k = 0; k < W; k++) {
             node.child[k] = kEmptyChild;
             for (int a = 0; a < 3; a++) { node.lo[k][a] = kInf; node.hi[k][a] = -kInf; }
         }
@@ -235,13 +236,15 @@ struct Collapser {
 };
 }  // namespace
 
-Bvh4Build collapse_bvh4(const BvhBuild& b2) {
-    Collapser c{b2, {}};
-    c.out.nodes.reserve(b2.nodes.size() / 2 + 4);
+namespace {
+template <int W>
+BvhNBuild<W> collapse(const BvhBuild& b2) {
+    Collapser<W> c{b2, {}};
+    c.out.nodes.reserve(b2.nodes.size() / (W == 4 ? 2 : 3) + 4);
     c.build(0, 0, 0);
     for (int a = 0; a < 3; a++) { c.out.root_lo[a] = kInf; c.out.root_hi[a] = -kInf; }
-    const BuildNode4& r = c.out.nodes[0];
-    for (int k = 0; k < 4; k++)
+    const BuildNodeN<W>& r = c.out.nodes[0];
+    for (int k = 0; k < W; k++)
         if (r.child[k] != kEmptyChild)
             for (int a = 0; a < 3; a++) {
                 c.out.root_lo[a] = std::min(c.out.root_lo[a], r.lo[k][a]);
@@ -249,5 +252,8 @@ Bvh4Build collapse_bvh4(const BvhBuild& b2) {
             }
     return std::move(c.out);
 }
+}  // namespace
+
+Bvh4Build collapse_bvh4(const BvhBuild& b2) { return collapse<4>(b2); }
 
 }  // namespace rt

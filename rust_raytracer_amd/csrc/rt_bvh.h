@@ -31,19 +31,24 @@ BvhBuild build_bvh(const double* positions, const uint32_t* tri_pos, uint32_t n_
 bool build_bvh_device(const double* positions, uint32_t n_positions, const uint32_t* tri_pos, uint32_t n_tris, uint32_t max_leaf,
                       BvhBuild* out, std::string* err);
 
-// 4-wide collapse of a BVH2 (same leaves, same triangle order): every node holds up to four
-// children, obtained by repeatedly replacing the inner child of largest surface area by its two
-// children.  One node fetch then decides four boxes: about half the dependent fetches per ray.
-struct BuildNode4 {
-    double lo[4][3], hi[4][3];
-    int32_t child[4];  // same encoding as BuildNode::c0 (inner index into nodes4 / leaf code / kEmptyChild)
+// W-wide collapse of a BVH2 (same leaves, same triangle order): every node holds up to W children,
+// obtained by repeatedly replacing the inner child of largest surface area by its two children.  One node
+// fetch then decides W boxes: about half the dependent fetches per ray for W = 4 (W = 8 was tried with quantised
+// nodes and was slower: profiles/r02/ab/node_width_and_size.txt).
+template <int W>
+struct BuildNodeN {
+    double lo[W][3], hi[W][3];
+    int32_t child[W];  // same encoding as BuildNode::c0 (inner index into the wide node array / leaf code / kEmptyChild)
 };
-struct Bvh4Build {
-    std::vector<BuildNode4> nodes;  // nodes[0] is the root
-    uint32_t max_depth = 0;         // inner levels
-    uint32_t max_stack = 0;         // worst-case traversal stack entries (sum over a root-leaf path of children-1) + 1
+template <int W>
+struct BvhNBuild {
+    std::vector<BuildNodeN<W>> nodes;  // nodes[0] is the root
+    uint32_t max_depth = 0;            // inner levels
+    uint32_t max_stack = 0;            // worst-case traversal stack entries (sum over a root-leaf path of children-1) + 1
     double root_lo[3], root_hi[3];
 };
+using BuildNode4 = BuildNodeN<4>;
+using Bvh4Build = BvhNBuild<4>;
 Bvh4Build collapse_bvh4(const BvhBuild& bvh2);
 
 }  // namespace rt

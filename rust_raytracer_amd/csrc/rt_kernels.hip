@@ -304,6 +304,80 @@ struct DeviceScene {
                 }
             }
         }
+        // Quantised nodes: the padded child boxes (as in BvhNode4f: 2^-19 S, rounded outward to f32) on a per-node 8-bit
+        // grid, rounded outward on the grid.  k_wf_mesh evaluates t = fma(q, cell * iv, fma(org, iv, -o * iv)): cell is a
+        // power of two (cell * iv exact), so against the f32-node test (fma(plane, iv, -o * iv)) there is one more rounding,
+        // of a value bounded by 2 S |iv|; with it the error is < 2.5 x 2^-23 S |iv| per plane, inside the padding.
+        std::vector<BvhNode4q> nodes4q(cs.nodes4.size());
+        {
+            auto pad_of = [&]() {
+                std::vector<std::pair<uint32_t, double>> pads;
+                size_t inst = 0;
+                for (const MeshInst& mi : cs.meshes) {
+                    const Bounds<double>& b = cs.mesh_bounds[inst++];
+                    double S = 0.0;
+                    for (int a = 0; a < 3; a++) S = std::fmax(S, std::fmax(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
+                    if (!std::isfinite(S)) S = 0.0;
+                    pads.emplace_back(mi.node4_base, S * (1.0 / 524288.0));
+                }
+                std::sort(pads.begin(), pads.end());
+                return pads;
+            };
+            // one node: W children, words = W / 4 grid words per axis
+            auto quantise = [](int W, const double (*lo)[3], const double (*hi)[3], const int32_t* child, double m, float* org_out,
+                               float* cell_out, uint32_t* qlo, uint32_t* qhi, int32_t* child_out) -> bool {
+                const int words = W / 4;
+                for (int a = 0; a < 3; a++) {
+                    double flo[8], fhi[8];
+                    bool real[8];
+                    double lo_min = INFINITY, hi_max = -INFINITY;
+                    for (int k = 0; k < W; k++) {
+                        real[k] = child[k] != kEmptyChild && lo[k][a] <= hi[k][a];
+                        if (!real[k]) continue;
+                        flo[k] = double(round_down<float>(lo[k][a] - m));
+                        fhi[k] = double(round_up<float>(hi[k][a] + m));
+                        lo_min = std::fmin(lo_min, flo[k]);
+                        hi_max = std::fmax(hi_max, fhi[k]);
+                    }
+                    const bool any = lo_min <= hi_max && std::isfinite(lo_min) && std::isfinite(hi_max);
+                    const double org = any ? lo_min : 0.0;  // an f32 value
+                    const double ext = any ? hi_max - org : 0.0;
+                    int e = -100;
+                    if (ext > 0.0) {
+                        e = int(std::ceil(std::log2(ext / 255.0)));
+                        while (ext / std::ldexp(1.0, e) > 255.0) e++;
+                        while (e > -100 && ext / std::ldexp(1.0, e - 1) <= 255.0) e--;
+                        e = std::max(-100, std::min(e, 120));
+                    }
+                    const double cell = std::ldexp(1.0, e);
+                    org_out[a] = float(org);
+                    cell_out[a] = float(cell);
+                    for (int w = 0; w < words; w++) { qlo[a * words + w] = 0; qhi[a * words + w] = 0; }
+                    for (int k = 0; k < W; k++) {
+                        uint32_t ql = 255u, qh = 0u;  // empty child: lo > hi, never entered
+                        if (any && real[k]) {
+                            double l = std::floor((flo[k] - org) / cell), h = std::ceil((fhi[k] - org) / cell);
+                            ql = uint32_t(std::max(0.0, std::min(l, 255.0)));
+                            qh = uint32_t(std::max(0.0, std::min(h, 255.0)));
+                            if (!(org + ql * cell <= flo[k] && org + qh * cell >= fhi[k])) return false;  // e > 120: coordinates beyond 1e38
+                        }
+                        qlo[a * words + (k >> 2)] |= ql << (8 * (k & 3));
+                        qhi[a * words + (k >> 2)] |= qh << (8 * (k & 3));
+                    }
+                }
+                for (int k = 0; k < W; k++) child_out[k] = child[k];
+                return true;
+            };
+            const auto pads4 = pad_of();
+            size_t pi = 0;
+            for (size_t i = 0; i < nodes4q.size(); i++) {
+                while (pi + 1 < pads4.size() && pads4[pi + 1].first <= i) pi++;
+                const BuildNode4& sn = cs.nodes4[i];
+                BvhNode4q& qn = nodes4q[i];
+                if (!quantise(4, sn.lo, sn.hi, sn.child, pads4.empty() ? 0.0 : pads4[pi].second, qn.org, qn.cell, qn.qlo, qn.qhi, qn.child))
+                    return set_err(RT_E_UNSUPPORTED, "BVH node does not fit the 8-bit grid");
+            }
+        }
         std::vector<Bounds<R>> mesh_bounds(cs.mesh_bounds.size());
         for (size_t i = 0; i < mesh_bounds.size(); i++)
             for (int a = 0; a < 3; a++) {  // outward: this box only decides which rays are queued for the mesh
@@ -369,6 +443,7 @@ struct DeviceScene {
         if ((st = buf.upload(volumes, &view.volumes)) != RT_OK) return st;
         if ((st = buf.upload(nodes, &view.nodes)) != RT_OK) return st;
         if ((st = buf.upload(nodes4, &view.nodes4)) != RT_OK) return st;
+        if ((st = buf.upload(nodes4q, &view.nodes4q)) != RT_OK) return st;
         if ((st = buf.upload(mesh_bounds, &view.mesh_bounds)) != RT_OK) return st;
         if ((st = buf.upload(tris, &view.tris)) != RT_OK) return st;
         if ((st = buf.upload(tris32, &view.tris32)) != RT_OK) return st;
@@ -712,12 +787,17 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     // (not for the texture-interpreter variant: fused it needs more than 256 VGPRs, i.e. one wave per SIMD)
     const bool fuse = (split || prims_only) && !s->compiled.needs_tex_interpreter && env_u32("RT_WF_FUSE", 0) != 0;  // measured slower than the separate pass (profiles/r02/ab/fuse_prims_into_shade.txt): off by default
     // k_wf_mesh keeps (child, entry distance) pairs: a shallow LDS part (occupancy) + a global spill part
+    // BVH node format of k_wf_mesh: 1 = 4-wide quantised (BvhNode4q, 64 B, default), 0 = 4-wide f32 (BvhNode4f, 128 B; A/B).
+    // An 8-wide quantised node (a third fewer visits) was slower: profiles/r02/ab/node_width_and_size.txt.
+    const int node_kind = env_u32("RT_WF_NODES", 1) != 0 ? 1 : 0;
     const int mesh_levels = int(s->compiled.max_bvh4_stack) + 1;
     const int lds_levels = std::min<int>(mesh_levels, int(env_u32("RT_WF_LDS_LEVELS", 12)));
     const size_t lds_mesh = size_t(lds_levels) * 256 * sizeof(uint2) + 4 * kMeshWaveLds<R>;
     if (split) {
-        if (stats) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_mesh<R, true>, 256, lds_mesh));
-        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_mesh<R, false>, 256, lds_mesh));
+#define RT_MESH_OCC(ST, ND) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_mesh<R, ST, ND>, 256, lds_mesh))
+        if (stats) { if (node_kind == 1) RT_MESH_OCC(true, 1); else RT_MESH_OCC(true, 0); }
+        else { if (node_kind == 1) RT_MESH_OCC(false, 1); else RT_MESH_OCC(false, 0); }
+#undef RT_MESH_OCC
         if (blocks_per_cu < 1) blocks_per_cu = 1;
         blocks_per_cu = std::min<int>(blocks_per_cu, int(env_u32("RT_WF_MESH_BLOCKS", 64)));  // experiments: occupancy scaling
     }
@@ -796,6 +876,12 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
             RT_LAUNCH_PRIMS_ANY();
             HIP_TRY(hipEventRecord(w.events[1], stream));
         }
+#define RT_LAUNCH_MESH_V(ST, ND, QUEUE, NPTR, CPTR) hipLaunchKernelGGL((k_wf_mesh<R, ST, ND>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, QUEUE, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels, NPTR, CPTR)
+#define RT_LAUNCH_MESH(QUEUE, NPTR, CPTR)                                                                                                         \
+    do {                                                                                                                                          \
+        if (stats) { if (node_kind == 1) RT_LAUNCH_MESH_V(true, 1, QUEUE, NPTR, CPTR); else RT_LAUNCH_MESH_V(true, 0, QUEUE, NPTR, CPTR); } \
+        else { if (node_kind == 1) RT_LAUNCH_MESH_V(false, 1, QUEUE, NPTR, CPTR); else RT_LAUNCH_MESH_V(false, 0, QUEUE, NPTR, CPTR); }       \
+    } while (0)
         bool first_round = true;
         for (;;) {
             size_t ev = 0;
@@ -812,16 +898,15 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
                         if (stats) {
                             hipLaunchKernelGGL((k_wf_mesh32<R, true>), dim3(mesh32_blocks), dim3(256), lds_mesh32, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels32);
                             hipLaunchKernelGGL((k_wf_mesh_exact<R, true>), chunks, dim3(256), 0, stream, ds.view, pool, w.mesh_queue, w.fallback_queue, w.d_ctr, s->d_counters, mesh_pc);
-                            hipLaunchKernelGGL((k_wf_mesh<R, true>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, w.fallback_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels, &w.d_ctr->n_fallback, &w.d_ctr->cursor_fb);
+                            RT_LAUNCH_MESH(w.fallback_queue, &w.d_ctr->n_fallback, &w.d_ctr->cursor_fb);
                         } else {
                             hipLaunchKernelGGL((k_wf_mesh32<R, false>), dim3(mesh32_blocks), dim3(256), lds_mesh32, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels32);
                             hipLaunchKernelGGL((k_wf_mesh_exact<R, false>), chunks, dim3(256), 0, stream, ds.view, pool, w.mesh_queue, w.fallback_queue, w.d_ctr, s->d_counters, mesh_pc);
-                            hipLaunchKernelGGL((k_wf_mesh<R, false>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, w.fallback_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels, &w.d_ctr->n_fallback, &w.d_ctr->cursor_fb);
+                            RT_LAUNCH_MESH(w.fallback_queue, &w.d_ctr->n_fallback, &w.d_ctr->cursor_fb);
                         }
-                    } else if (stats)
-                        hipLaunchKernelGGL((k_wf_mesh<R, true>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels, &w.d_ctr->n_mesh, &w.d_ctr->cursor);
-                    else
-                        hipLaunchKernelGGL((k_wf_mesh<R, false>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels, &w.d_ctr->n_mesh, &w.d_ctr->cursor);
+                    } else {
+                        RT_LAUNCH_MESH(w.mesh_queue, &w.d_ctr->n_mesh, &w.d_ctr->cursor);
+                    }
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 } else {
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
@@ -890,6 +975,8 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
         }
 #undef RT_LAUNCH_PRIMS_ANY
 #undef RT_LAUNCH_PRIMS
+#undef RT_LAUNCH_MESH
+#undef RT_LAUNCH_MESH_V
         hipLaunchKernelGGL(k_wf_resolve, dim3(uint32_t((npix + 255) / 256)), dim3(256), 0, stream, w.sample_L, w.acc, npix, strata, nrep,
                            pv.spp, int(t0 == 0), d_out, int(t0 + nrep >= T));
     }
@@ -924,7 +1011,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     st.node_visits = hc.node_visits;
     st.tri_tests = hc.tri_tests;
     st.prim_tests = hc.prim_tests;
-    st.bytes_node = split ? sizeof(BvhNode4f) : sizeof(BvhNode<R>);
+    st.bytes_node = split ? (mesh32 || node_kind == 0 ? sizeof(BvhNode4f) : sizeof(BvhNode4q)) : sizeof(BvhNode<R>);
     st.bytes_tri = sizeof(TriRec<R>);
     st.bytes_attr = sizeof(TriAttr<R>);
     // path state moved by the DOMINANT kernel per ray it traverses: ray (6 R) + bound/op read (R + 4)

@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256, RT_MESH32_WAVES) k_wf_mesh32(SceneView<R>
                                                                      uint2* __restrict__ spill, int lds_levels) {
     extern __shared__ uint2 lds_stack2[];
     MeshStack stk;
-    stk.lds = lds_stack2 + threadIdx.x;
+    stk.lds = (LdsU64*)(lds_stack2 + threadIdx.x);
     const uint32_t lane = threadIdx.x & 63u;
     char* wave_area = reinterpret_cast<char*>(lds_stack2 + size_t(lds_levels) * 256) + (threadIdx.x >> 6) * kMesh32WaveLds;
     uint16_t* pair_tbl = reinterpret_cast<uint16_t*>(wave_area);

@@ -112,6 +112,22 @@ struct alignas(128) BvhNode4f {
     uint32_t _pad[4];
 };
 
+// The same node in 64 B (four 16-B loads instead of seven): child boxes as 8-bit grid coordinates relative to a
+// per-node origin and per-axis power-of-two cell size (the compressed wide BVH node of Ylitie, Karras, Laine 2017,
+// 4-wide here).  A wave whose lanes read 64 different nodes pays one L1 cycle per lane and LOAD INSTRUCTION
+// (tools/micro_l1.hip: 64 clk per 16-B wave load, 449 clk per visit of a 7-load record, 291 of a 4-load one), which is
+// what bounds k_wf_mesh.  Decoded plane = org + q * cell, q_lo rounded down and q_hi up on the grid from the boxes
+// of BvhNode4f (padding included), so the quantised box contains the padded f32 box; the decode's own rounding
+// (one fma per plane) stays inside that padding (see the node builder in rt_kernels.hip).
+struct alignas(64) BvhNode4q {
+    float org[3];      // grid origin (<= every child's lo)
+    float cell[3];     // 2^e per axis
+    uint32_t qlo[3];   // per axis: child k's lower grid coordinate in byte k
+    uint32_t qhi[3];   // upper; an empty child has qlo = 255 > qhi = 0
+    int32_t child[4];  // as in BvhNode4f
+};
+static_assert(sizeof(BvhNode4q) == 64, "BvhNode4q must be 64 bytes");
+
 // Triangle record for the intersection test: v0 and the two edges (mesh.rs:69-70 computes the
 // edges per test; v1 - v0 done once on the host in the same arithmetic gives the same bits).
 template <typename R>
@@ -199,7 +215,8 @@ struct SceneView {
     const MeshInst* meshes;
     const VolumeRec<R>* volumes;   // global memory (not in the LDS blob)
     const BvhNode<R>* nodes;
-    const BvhNode4f* nodes4;       // 4-wide f32 nodes (wavefront mesh kernel)
+    const BvhNode4f* nodes4;       // 4-wide f32 nodes (k_wf_mesh32, k_wf_mesh with RT_WF_NODES=0)
+    const BvhNode4q* nodes4q;      // the same nodes, quantised to 64 B (k_wf_mesh)
     const Bounds<R>* mesh_bounds;  // per mesh instance: exact box of its triangles (object space)
     const TriRec<R>* tris;
     const TriRec32* tris32;        // same slots, f32 (k_wf_mesh32)

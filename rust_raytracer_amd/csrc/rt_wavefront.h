@@ -55,6 +55,14 @@ template <typename T> RT_DEV T& at(T* base, uint32_t slot) {
     return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + slot * uint32_t(sizeof(T)));
 }
 
+// The same for a base pointer that was LOADED from memory (the device copy of the pool descriptor): the compiler cannot know
+// its address space and would emit flat_store; the cast says "global".
+template <typename T> RT_DEV void put_global(T* base, uint32_t slot, T v) {
+    typedef __attribute__((address_space(1))) char GChar;
+    typedef __attribute__((address_space(1))) T GT;
+    *reinterpret_cast<GT*>(reinterpret_cast<GChar*>((GT*)base) + slot * uint32_t(sizeof(T))) = v;
+}
+
 struct WfCounters {
     uint32_t n_in;        // entries of the current queue
     uint32_t n_out;       // entries appended to the next queue
@@ -580,25 +588,32 @@ RT_DEV float f32_at_least(float x) { return x + fabsf(x) * 9.5367431640625e-7f +
 // a private global spill area (`[level][global lane]`, coalesced).  A shallow LDS part keeps 4 blocks per CU
 // resident; the spill part is touched by a few percent of the pushes (worst case = BVH4 max_stack).
 // Measured (headline scene): 12 LDS levels 742 ms/step, 8: +5 %, 24: +20 %; 5 waves/SIMD spills and is slower.
+// The LDS part is addressed through an LDS-qualified pointer: with plain (generic) pointers hipcc merges the two stores of
+// `put` into one store through a selected pointer and then fails in the backend ("Illegal instruction detected:
+// V_CMP_NE_U32 0, src_shared_base") once a node step has more than a few puts (the 8-wide node has seven).
+typedef __attribute__((address_space(3))) unsigned long long LdsU64;
 struct MeshStack {
-    uint2* lds;        // + threadIdx.x
+    LdsU64* lds;       // + threadIdx.x
     uint2* spill;      // + global lane
     int lds_levels;
     uint32_t spill_stride;
     RT_DEV void put(int sp, int32_t child, float dist) const {
-        uint2 e = make_uint2(uint32_t(child), __float_as_uint(dist));
-        if (sp < lds_levels) lds[sp * 256] = e;
-        else spill[size_t(sp - lds_levels) * spill_stride] = e;
+        if (sp < lds_levels) lds[sp * 256] = (static_cast<unsigned long long>(__float_as_uint(dist)) << 32) | uint32_t(child);
+        else spill[size_t(sp - lds_levels) * spill_stride] = make_uint2(uint32_t(child), __float_as_uint(dist));
     }
     RT_DEV uint2 get(int sp) const {
-        if (sp < lds_levels) return lds[sp * 256];
+        if (sp < lds_levels) {
+            unsigned long long e = lds[sp * 256];
+            return make_uint2(uint32_t(e), uint32_t(e >> 32));
+        }
         return spill[size_t(sp - lds_levels) * spill_stride];
     }
 };
 
 template <typename R> constexpr uint32_t kMeshWaveLds = 1024u + 3u * 64u * uint32_t(sizeof(R));  // per wave, see k_wf_mesh
 
-template <typename R, bool STATS>
+// NODE: 0 = 4-wide f32 nodes (BvhNode4f, 128 B), 1 = 4-wide quantised nodes (BvhNode4q, 64 B)
+template <typename R, bool STATS, int NODE>
 __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc, WfPool<R> pool, const uint32_t* __restrict__ mesh_queue,
                                                                  WfCounters* __restrict__ ctr, DeviceCounters* counters,
                                                                  uint32_t refill_min, uint32_t inner_min, int32_t mesh_pc,
@@ -607,7 +622,7 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
     // n_ptr / cursor_ptr: length and hand-out cursor of `mesh_queue` (&ctr->n_mesh / &ctr->cursor, or the fallback queue's)
     extern __shared__ uint2 lds_stack2[];
     MeshStack stk;
-    stk.lds = lds_stack2 + threadIdx.x;
+    stk.lds = (LdsU64*)(lds_stack2 + threadIdx.x);
     // wave-private LDS behind the stack: pair table (512 x u16) + one result slot per lane (t, u, v)
     const uint32_t lane = threadIdx.x & 63u;
     char* wave_area = reinterpret_cast<char*>(lds_stack2 + size_t(lds_levels) * 256) + (threadIdx.x >> 6) * kMeshWaveLds<R>;
@@ -624,6 +639,7 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
     const MeshInst mi = sc.meshes[mop.arg];
     const Bounds<R> rb = sc.mesh_bounds[mop.arg];
     const BvhNode4f* nodes = sc.nodes4 + mi.node4_base;
+    const BvhNode4q* nodesq = sc.nodes4q + mi.node4_base;
     const TriRec<R>* tris = sc.tris + mi.tri_base;
     const bool hit_back = (mi.flags & RT_MESH_HIT_BACK_FACES) != 0;
     const R big = sizeof(R) == 8 ? R(1e150) : R(1e18);
@@ -728,25 +744,50 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
             if (uint32_t(__popcll(inner)) < inner_min && __ballot(has && node < 0) != 0ull) break;
             if (STATS) w_node++;
             if (has && node >= 0) {
-                const float4* nd = reinterpret_cast<const float4*>(nodes + node);
                 if (STATS) cnt.node_visits++;
-                const float4 nx = nd[nearx], fx = nd[3u - nearx];
-                const float4 ny = nd[neary], fy = nd[5u - neary];
-                const float4 nz = nd[nearz], fz = nd[7u - nearz];
-                const int4 cc = *reinterpret_cast<const int4*>(nd + 6);
+                const float miss = __builtin_huge_valf();
                 float nr[4];
-                int32_t ch[4] = {cc.x, cc.y, cc.z, cc.w};
-                const float nxa[4] = {nx.x, nx.y, nx.z, nx.w}, fxa[4] = {fx.x, fx.y, fx.z, fx.w};
-                const float nya[4] = {ny.x, ny.y, ny.z, ny.w}, fya[4] = {fy.x, fy.y, fy.z, fy.w};
-                const float nza[4] = {nz.x, nz.y, nz.z, nz.w}, fza[4] = {fz.x, fz.y, fz.z, fz.w};
+                int32_t ch[4];
+                if constexpr (NODE == 1) {
+                    // four 16-B loads; plane = org + q * cell, so t = q * (cell * iv) + (org * iv - o * iv)
+                    const uint4* nd = reinterpret_cast<const uint4*>(nodesq + node);
+                    const uint4 h0 = nd[0], h1 = nd[1], h2 = nd[2];
+                    const int4 cc = *reinterpret_cast<const int4*>(nd + 3);
+                    ch[0] = cc.x; ch[1] = cc.y; ch[2] = cc.z; ch[3] = cc.w;
+                    const float ax = __uint_as_float(h0.w) * ivx, ay = __uint_as_float(h1.x) * ivy, az = __uint_as_float(h1.y) * ivz;
+                    const float bx = fmaf(__uint_as_float(h0.x), ivx, -oix), by = fmaf(__uint_as_float(h0.y), ivy, -oiy), bz = fmaf(__uint_as_float(h0.z), ivz, -oiz);
+                    const bool negx = nearx != 0u, negy = neary != 1u, negz = nearz != 2u;
+                    const uint32_t qnx = negx ? h2.y : h1.z, qfx = negx ? h1.z : h2.y;
+                    const uint32_t qny = negy ? h2.z : h1.w, qfy = negy ? h1.w : h2.z;
+                    const uint32_t qnz = negz ? h2.w : h2.x, qfz = negz ? h2.x : h2.w;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    // explicit FMAs: the translation unit is built with -ffp-contract=off for the f64 parity arithmetic, but
-                    // this f32 test only culls (its rounding is inside the boxes' padding either way): 24 fewer instructions
-                    float tn = fmaxf(fmaxf(fmaf(nxa[k], ivx, -oix), fmaf(nya[k], ivy, -oiy)), fmaxf(fmaf(nza[k], ivz, -oiz), 0.0f));
-                    float tf = fminf(fminf(fmaf(fxa[k], ivx, -oix), fmaf(fya[k], ivy, -oiy)), fminf(fmaf(fza[k], ivz, -oiz), tmax32));
-                    bool h = (tn <= tf) && ch[k] != kEmptyChild;
-                    nr[k] = h ? tn : __builtin_huge_valf();
+                    for (int k = 0; k < 4; k++) {
+                        const float nxk = float((qnx >> (8 * k)) & 0xFFu), nyk = float((qny >> (8 * k)) & 0xFFu), nzk = float((qnz >> (8 * k)) & 0xFFu);
+                        const float fxk = float((qfx >> (8 * k)) & 0xFFu), fyk = float((qfy >> (8 * k)) & 0xFFu), fzk = float((qfz >> (8 * k)) & 0xFFu);
+                        float tn = fmaxf(fmaxf(fmaf(nxk, ax, bx), fmaf(nyk, ay, by)), fmaxf(fmaf(nzk, az, bz), 0.0f));
+                        float tf = fminf(fminf(fmaf(fxk, ax, bx), fmaf(fyk, ay, by)), fminf(fmaf(fzk, az, bz), tmax32));
+                        bool h = (tn <= tf) && ch[k] != kEmptyChild;
+                        nr[k] = h ? tn : miss;
+                    }
+                } else {
+                    const float4* nd = reinterpret_cast<const float4*>(nodes + node);
+                    const float4 nx = nd[nearx], fx = nd[3u - nearx];
+                    const float4 ny = nd[neary], fy = nd[5u - neary];
+                    const float4 nz = nd[nearz], fz = nd[7u - nearz];
+                    const int4 cc = *reinterpret_cast<const int4*>(nd + 6);
+                    ch[0] = cc.x; ch[1] = cc.y; ch[2] = cc.z; ch[3] = cc.w;
+                    const float nxa[4] = {nx.x, nx.y, nx.z, nx.w}, fxa[4] = {fx.x, fx.y, fx.z, fx.w};
+                    const float nya[4] = {ny.x, ny.y, ny.z, ny.w}, fya[4] = {fy.x, fy.y, fy.z, fy.w};
+                    const float nza[4] = {nz.x, nz.y, nz.z, nz.w}, fza[4] = {fz.x, fz.y, fz.z, fz.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        // explicit FMAs: the translation unit is built with -ffp-contract=off for the f64 parity arithmetic, but
+                        // this f32 test only culls (its rounding is inside the boxes' padding either way): 24 fewer instructions
+                        float tn = fmaxf(fmaxf(fmaf(nxa[k], ivx, -oix), fmaf(nya[k], ivy, -oiy)), fmaxf(fmaf(nza[k], ivz, -oiz), 0.0f));
+                        float tf = fminf(fminf(fmaf(fxa[k], ivx, -oix), fmaf(fya[k], ivy, -oiy)), fminf(fmaf(fza[k], ivz, -oiz), tmax32));
+                        bool h = (tn <= tf) && ch[k] != kEmptyChild;
+                        nr[k] = h ? tn : miss;
+                    }
                 }
                 // sort the four (entry distance, child) pairs, nearest first (5 compare-exchanges)
 #define RT_CE(a, b)                                                   \
@@ -756,7 +797,6 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
     }
                 RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2) RT_CE(1, 3) RT_CE(1, 2)
 #undef RT_CE
-                const float miss = __builtin_huge_valf();
                 if (nr[0] < miss) {
                     // farthest first, so that the nearest remaining child is popped first
                     if (nr[3] < miss) { stk.put(sp, ch[3], nr[3]); sp++; }
@@ -938,11 +978,11 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
                 // whole shading code to reuse them for these stores (22 VGPRs of a kernel that is occupancy-bound).
                 asm volatile("" ::: "memory");
                 const WfPool<R>& pw = *pool_dev;
-                at(pw.ox, slot) = ps.ray.o.x; at(pw.oy, slot) = ps.ray.o.y; at(pw.oz, slot) = ps.ray.o.z;
-                at(pw.dx, slot) = ps.ray.d.x; at(pw.dy, slot) = ps.ray.d.y; at(pw.dz, slot) = ps.ray.d.z;
-                at(pw.tr, slot) = ps.throughput.x; at(pw.tg, slot) = ps.throughput.y; at(pw.tb, slot) = ps.throughput.z;
-                at(pw.rng, slot) = rng.s;
-                at(pw.depth, slot) = ps.depth;
+                put_global(pw.ox, slot, ps.ray.o.x); put_global(pw.oy, slot, ps.ray.o.y); put_global(pw.oz, slot, ps.ray.o.z);
+                put_global(pw.dx, slot, ps.ray.d.x); put_global(pw.dy, slot, ps.ray.d.y); put_global(pw.dz, slot, ps.ray.d.z);
+                put_global(pw.tr, slot, ps.throughput.x); put_global(pw.tg, slot, ps.throughput.y); put_global(pw.tb, slot, ps.throughput.z);
+                put_global(pw.rng, slot, rng.s);
+                put_global(pw.depth, slot, ps.depth);
                 alive = true;
                 if constexpr (FUSE) {
                     Best<R> nb;

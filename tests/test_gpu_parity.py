@@ -240,15 +240,16 @@ def test_every_kernel_variant_is_bit_identical(dev, name, monkeypatch):
     p.pipeline = api.RT_PIPELINE_WAVEFRONT
     for stats in (0, 1):
         for lds in ("1", "0"):
-            for split, fuse, mesh32 in (("1", "0", "0"), ("1", "1", "0"), ("1", "0", "1"), ("0", "0", "0")):
+            for split, fuse, mesh32, nodeq in (("1", "0", "0", "1"), ("1", "0", "0", "0"), ("1", "1", "0", "1"), ("1", "0", "1", "1"), ("0", "0", "0", "1")):
                 monkeypatch.setenv("RT_LDS_TABLES", lds)
+                monkeypatch.setenv("RT_WF_NODES", nodeq)  # BVH nodes of k_wf_mesh: 1 = 64-B quantised (default), 0 = 128-B f32
                 monkeypatch.setenv("RT_WF_SPLIT", split)
                 monkeypatch.setenv("RT_WF_FUSE", fuse)    # primitive program inside k_wf_shade instead of a separate pass
                 monkeypatch.setenv("RT_WF_MESH32", mesh32)  # two-stage mesh search: conservative f32 traversal + exact tests on the candidates
                 p.collect_stats = stats
                 wf = scene.render(hs.camera, p)
                 same = (wf == mega) | (np.isnan(wf) & np.isnan(mega))
-                assert same.all(), f"variant stats={stats} lds={lds} split={split} fuse={fuse} mesh32={mesh32}: {int((~same).any(axis=2).sum())} pixels differ"
+                assert same.all(), f"variant stats={stats} lds={lds} split={split} fuse={fuse} mesh32={mesh32} nodeq={nodeq}: {int((~same).any(axis=2).sum())} pixels differ"
 
 
 def test_stats_counters_and_collect_flag(dev):
@@ -260,7 +261,7 @@ def test_stats_counters_and_collect_flag(dev):
     st = scene.stats()
     assert st.samples == hs.width * hs.height * hs.spp
     assert st.rays >= st.samples and st.mesh_rays > 0 and st.node_visits > st.mesh_rays and st.tri_tests > 0
-    assert st.kernel_ms > 0 and st.bytes_node == 128 and st.bytes_tri == 80
+    assert st.kernel_ms > 0 and st.bytes_node == 64 and st.bytes_tri == 80   # 4-wide nodes quantised to 64 B
     assert st.pipeline_used == api.RT_PIPELINE_WAVEFRONT     # AUTO picks the wavefront scheduler for mesh scenes
     q = p.copy()
     q.pipeline = api.RT_PIPELINE_MEGAKERNEL
