@@ -252,6 +252,64 @@ def test_every_kernel_variant_is_bit_identical(dev, name, monkeypatch):
                 assert same.all(), f"variant stats={stats} lds={lds} split={split} fuse={fuse} mesh32={mesh32} nodeq={nodeq}: {int((~same).any(axis=2).sum())} pixels differ"
 
 
+def _bumpy_grid_obj(path, n, offset, scale, flat=False):
+    """An n x n grid of quads (2 n^2 triangles) over [-1, 1]^2 with a sine bump, then scaled per axis and moved: the
+    coordinates a quantised BVH node has to cover (large offsets, anisotropic and zero extents)."""
+    lines = ["vt 0 0"]
+    for j in range(n + 1):
+        for i in range(n + 1):
+            x, z = -1 + 2 * i / n, -1 + 2 * j / n
+            y = 0.0 if flat else float(0.25 * np.sin(3.1 * x) * np.cos(2.3 * z) + 0.05 * np.sin(17 * x + 5 * z))
+            lines.append(f"v {x * scale[0] + offset[0]!r} {y * scale[1] + offset[1]!r} {z * scale[2] + offset[2]!r}")
+            lines.append("vn 0 1 0")
+    idx = lambda i, j: j * (n + 1) + i + 1
+    for j in range(n):
+        for i in range(n):
+            a, b, c, d = idx(i, j), idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)
+            lines.append(f"f {a}/1/{a} {c}/1/{c} {b}/1/{b}")
+            lines.append(f"f {a}/1/{a} {d}/1/{d} {c}/1/{c}")
+    path.write_text("\n".join(lines) + "\n")
+
+
+@pytest.mark.parametrize("case", ["far_from_origin", "anisotropic", "flat", "tiny"])
+def test_quantised_bvh_nodes_on_awkward_meshes(dev, tmp_path, monkeypatch, case):
+    """k_wf_mesh culls with 64-B nodes whose child boxes are 8-bit grid coordinates (BvhNode4q).  The grid must contain
+    the padded boxes whatever the mesh's coordinates look like: far from the origin (large origin, small cells), three
+    orders of magnitude between the axes, zero extent on an axis, and small coordinates (0.02 units: at 1e-3 the
+    REFERENCE's octree, restated by the oracle, never separates the triangles and runs out of memory).  Every frame must match the
+    oracle (a box that is too small loses hits) and the frame of the unquantised f32 nodes bit for bit."""
+    offset, scale, cam, target = {
+        "far_from_origin": ((1000.0, 0.0, -2000.0), (1.0, 1.0, 1.0), "1000,1.5,-1997", "1000,0,-2000"),
+        "anisotropic": ((0.0, 0.0, 0.0), (50.0, 0.02, 1.0), "0,20,30", "0,0,0"),
+        "flat": ((0.0, 0.25, 0.0), (1.0, 1.0, 1.0), "0,1.5,3", "0,0.25,0"),
+        "tiny": ((0.0, 0.0, 0.0), (0.02, 0.02, 0.02), "0,0.03,0.06", "0,0,0"),
+    }[case]
+    _bumpy_grid_obj(tmp_path / "grid.obj", 24, offset, scale, flat=(case == "flat"))
+    s = max(scale)
+    lx, ly, lz = offset[0] - 0.5 * s, offset[1] + 2.0 * s, offset[2] - 0.5 * s
+    scene = tmp_path / "scene"
+    scene.write_text(f"@config output_width = 40\n@config aspect_ratio = 1\n@config focal_length = 40\n"
+                     f"@config camera_pos = {cam}\n@config camera_target = {target}\n"
+                     f"grid: mesh grid.obj (glossy (constant 0.7,0.6,0.3) (constant 0.3))\n"
+                     f"lamp: plane {lx!r},{ly!r},{lz!r} {s!r},0,0 0,0,{s!r} (emissive (constant 8,8,8)) backface\n"
+                     f"sky: sky (constant 0.3,0.4,0.6)\nworld: list $grid $lamp $sky\nlights: list $lamp\n")
+    hs = api.HostScene([str(scene), "-s=16", "--seed=21"])
+    ref, _ = pyoracle.render(hs.desc, hs.camera, hs.params)
+    assert np.isfinite(ref[..., :3]).all() and ref[..., :3].std() > 0.01   # the mesh is in view and lit
+    p = hs.params.copy()
+    p.pipeline = api.RT_PIPELINE_WAVEFRONT
+    p.collect_stats = 1
+    frames = {}
+    for nodes in ("1", "0"):
+        monkeypatch.setenv("RT_WF_NODES", nodes)
+        dscene = api.DeviceScene(hs.desc, 0)
+        frames[nodes] = dscene.render(hs.camera, p)
+        st = dscene.stats()
+        assert st.mesh_rays > 0 and st.tri_tests > 0 and st.bytes_node == (64 if nodes == "1" else 128)
+        assert_f64_parity(frames[nodes], ref)
+    np.testing.assert_array_equal(frames["1"], frames["0"])
+
+
 def test_stats_counters_and_collect_flag(dev):
     hs = api.HostScene(SCENES["light_test"])
     scene = api.DeviceScene(hs.desc, 0)
