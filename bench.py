@@ -249,6 +249,10 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--spp-divisor", type=int, default=1, help="debug: render spp/divisor (result is then labelled reduced)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="device scenes of the frame pipeline (api.FramePipeline): 1 = the timed frames strictly one after the other; "
+                         "default 1 on one GPU, 3 with --gpus > 1 (frame k+1 starts under the tail of frame k)")
+    ap.add_argument("--no-overlap", action="store_true", help="same as --frames-in-flight 1")
     ap.add_argument("--save-png", default="")
     a = ap.parse_args()
     if a.gpus < 1:
@@ -295,38 +299,50 @@ def main():
         s = int([x for x in args if x.startswith("-s=")][0][3:]) // a.spp_divisor
         args = [x for x in args if not x.startswith("-s=")] + [f"-s={s}"]
     hs = api.HostScene(args + [f"--seed={a.seed}", f"--precision={a.precision}", f"--pipeline={a.pipeline}"])
-    scene = api.DeviceScene(hs.desc, local_rank)  # BVH build + upload: resident before timing
+    # The K timed steps are K frames of the same job.  On one GPU they are rendered one after the other.  A rank of a multi-GPU
+    # run renders 1/N of the rows, and the end of such a render — the last, longest paths: 20 of its 44 iterations at N = 8 — is
+    # a chain of small latency-bound launches that costs 10-14 % of the share (tools/gpu_partscale.py).  There the frames go
+    # through api.FramePipeline: three device scenes (three pools, three streams, one host thread each), frame k+1 starts as
+    # soon as frame k has entered its tail (rt_scene_set_tail_flag).  Every frame is rendered completely and gathered inside
+    # the timed region; only the tails overlap the next frame's start (measured on a 1/8 share: 173 -> 166 ms per frame,
+    # tools/gpu_pipeline_probe.py; nothing to gain on a whole frame, where the tail is 2 %).
+    depth = a.frames_in_flight if a.frames_in_flight > 0 else (3 if world > 1 else 1)
+    if a.no_overlap or a.steps < 2:
+        depth = 1
+    pipe = api.FramePipeline(hs.desc, local_rank, depth)  # BVH build + upload: resident before timing
+    scene = pipe.scenes[0]
     params = rtdist.partition_params(hs.params, world, rank, hs.height)
     rows = len(rtdist.rows_of_part(hs.height, world, rank))
-    out = torch.empty((rows, hs.width, 4), dtype=torch.float64, device=device)
-    stream = torch.cuda.current_stream(device)
+    n_warm = max(a.warmup, depth)  # every device scene of the pipeline renders at least one untimed frame (pool allocation)
+    n_buf = max(a.steps, n_warm)
+    outs = [torch.empty((rows, hs.width, 4), dtype=torch.float64, device=device) for _ in range(n_buf)]
+    streams = [torch.cuda.Stream(device) for _ in range(depth)]
+    stream_handles = [st.cuda_stream for st in streams]
 
     frame_holder = {}
 
-    def step(collect_stats=False):
-        p = params.copy()
-        p.collect_stats = 1 if collect_stats else 0
-        scene.render_device(hs.camera, p, out.data_ptr(), stream.cuda_stream)
-        frame_holder["frame"] = rtdist.gather_frame(out, hs.height, hs.width)
+    def run(n_frames, collect_first=False):
+        plist = []
+        for k in range(n_frames):
+            p = params.copy()
+            p.collect_stats = 1 if (collect_first and k == 0) else 0
+            plist.append(p)
+        stats = pipe.render_frames(hs.camera, plist, [outs[k].data_ptr() for k in range(n_frames)], stream_handles)
+        for k in range(n_frames):  # the renders have returned (stream-synchronised by the library): one gather per frame
+            frame_holder["frame"] = rtdist.gather_frame(outs[k], hs.height, hs.width)
+        return stats
 
     # Warmup; the first warmup step also collects the traversal counters (deterministic for a
     # given seed/config) that turn kernel time into algorithmic bytes.
-    counters = None
-    for i in range(max(a.warmup, 1)):  # --warmup 0 still gets the one untimed counter-collecting step
-        step(collect_stats=(i == 0))
-        if i == 0:
-            counters = scene.stats()
+    counters = run(n_warm, collect_first=True)[0]  # --warmup 0 still gets the untimed counter-collecting step(s)
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    kstats = []  # per timed step: HIP-event sums per kernel (library side, on the render stream) + launch counts
-    for _ in range(a.steps):
-        step()
-        st_ = scene.stats()
-        kstats.append({"traversal": st_.traversal_kernel_ms, "prims": st_.prims_kernel_ms, "shade": st_.shade_kernel_ms,
-                       "all": st_.kernel_ms, "launches": max(st_.n_launches, 1)})
+    # per timed step: HIP-event sums per kernel (library side, on the render's stream) + launch counts
+    kstats = [{"traversal": st_.traversal_kernel_ms, "prims": st_.prims_kernel_ms, "shade": st_.shade_kernel_ms,
+               "all": st_.kernel_ms, "launches": max(st_.n_launches, 1)} for st_ in run(a.steps)]
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -359,7 +375,7 @@ def main():
             "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": desc + (f" [DEBUG spp/{a.spp_divisor}]" if a.spp_divisor > 1 else ""),
                        "image": [hs.width, hs.height], "spp": hs.spp, "seed": a.seed,
-                       "pipeline": a.pipeline, "partition": f"{params.band_rows or hs.height}-row bands round-robin over {world} GPU(s)"
+                       "pipeline": a.pipeline, "frames_in_flight": depth, "untimed_frames": n_warm, "partition": f"{params.band_rows or hs.height}-row bands round-robin over {world} GPU(s)"
                                     + (" [REHEARSAL: all ranks on one device, gloo]" if one_device else "")},
             "roofline": roofline, "cpu_baseline": cpu,
         }

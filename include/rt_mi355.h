@@ -281,6 +281,15 @@ int rt_scene_info(const RtSceneDesc* desc, uint32_t* flags_out);
  * out[5] scene-program ops, out[6] sphere / quad groups re-built as SAH trees, out[7] primitives in them. */
 int rt_scene_mesh_stats(const RtSceneDesc* desc, uint64_t out[8]);
 
+/* Frame pipelining (no counterpart in the reference, which renders one image per process run): while `flag` is set
+ * (non-NULL), every rt_render / rt_render_device of this scene object stores 1 to `*flag` as soon as the render can no
+ * longer fill the GPU — all samples started, pool slots running empty (wavefront scheduler, last replica group) — and
+ * at the latest when the call returns, with or without an error.  A second RtScene created from the same description,
+ * driven from another host thread on another stream, can start the NEXT frame at that moment: its full launches run
+ * underneath the first render's tail (a chain of small, latency-bound launches: 10 % of a 1/8-frame share).  The caller
+ * clears `*flag` before each render.  rust_raytracer_amd.api.FramePipeline and bench.py use it. */
+int rt_scene_set_tail_flag(RtScene* scene, int32_t* flag);
+
 /* Message for the last non-RT_OK status on this thread ("" if none). */
 const char* rt_last_error(void);
 

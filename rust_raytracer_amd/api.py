@@ -212,6 +212,9 @@ def load_device_lib() -> C.CDLL:
         lib.rt_debug_trace_sample.restype = C.c_int
         lib.rt_scene_info.argtypes = [C.POINTER(RtSceneDesc), C.POINTER(C.c_uint32)]
         lib.rt_scene_info.restype = C.c_int
+        if hasattr(lib, "rt_scene_set_tail_flag"):  # absent from older A/B builds loaded through RT_DEVICE_LIB
+            lib.rt_scene_set_tail_flag.argtypes = [C.c_void_p, C.c_void_p]
+            lib.rt_scene_set_tail_flag.restype = C.c_int
         if hasattr(lib, "rt_scene_mesh_stats"):  # absent from older A/B builds loaded through RT_DEVICE_LIB
             lib.rt_scene_mesh_stats.argtypes = [C.POINTER(RtSceneDesc), C.POINTER(C.c_uint64)]
             lib.rt_scene_mesh_stats.restype = C.c_int
@@ -386,3 +389,76 @@ class DeviceScene:
             self.close()
         except Exception:
             pass
+
+
+class FramePipeline:
+    """A sequence of frames of one scene on one GPU with their tails overlapped (rt_scene_set_tail_flag, include/rt_mi355.h).
+
+    The end of a render is a chain of small, latency-bound launches (the last, longest paths: 20 of the 44 iterations of a
+    1/8-frame share, 10 % of its time) that no scheduling inside ONE frame can fill.  Here `depth` device scenes of the
+    same description are driven by one host thread each, on one stream each; frame k starts when frame k-1 reports that
+    it has entered its tail, so its full launches run underneath.  Every frame is the frame DeviceScene.render_device
+    produces on its own (same kernels, same per-sample RNG keys): tests/test_gpu_parity.py::test_frame_pipeline_*.
+    """
+
+    def __init__(self, desc, device: int = 0, depth: int = 2):
+        self.scenes = [DeviceScene(desc, device) for _ in range(max(1, depth))]
+        self.device = device
+
+    @property
+    def depth(self) -> int:
+        return len(self.scenes)
+
+    def render_frames(self, camera: RtCameraDesc, params_list, d_out_ptrs, streams):
+        """Frame k: params_list[k] into device buffer d_out_ptrs[k]; streams: one raw stream handle per device scene (all
+        different, none the NULL stream).  Blocks until every frame is rendered; returns one RtRenderStats per frame."""
+        import threading
+        import time
+        n, depth = len(params_list), len(self.scenes)
+        if len(d_out_ptrs) != n or len(streams) < depth:
+            raise ValueError("render_frames: one output buffer per frame and one stream per device scene")
+        flags = (C.c_int32 * max(n, 1))()  # flags[k]: frame k has entered its tail (or returned)
+        log = os.environ.get("RT_PIPE_LOG", "0") == "1"
+        t_origin = time.perf_counter()
+        stats = [None] * n
+        errors = []
+
+        def worker(i):
+            sc = self.scenes[i]
+            lib = sc._lib
+            k = i
+            try:
+                while k < n:
+                    if k > 0:
+                        while flags[k - 1] == 0 and not errors:
+                            time.sleep(0.0002)
+                    if errors:
+                        break
+                    lib.rt_scene_set_tail_flag(sc._h, C.addressof(flags) + 4 * k)
+                    t_start = time.perf_counter()
+                    sc.render_device(camera, params_list[k], d_out_ptrs[k], streams[i])
+                    stats[k] = sc.stats()
+                    if log:
+                        sys.stderr.write(f"[frame pipeline] frame {k} on scene {i}: start {1e3 * (t_start - t_origin):.1f} ms, "
+                                         f"end {1e3 * (time.perf_counter() - t_origin):.1f} ms, kernels {stats[k].kernel_ms:.1f} ms\n")
+                    k += depth
+            except Exception as e:  # noqa: BLE001 - reported to the caller below
+                errors.append(e)
+            finally:
+                for j in range(k, n, depth):  # frames this thread will not render: nobody may wait for them
+                    flags[j] = 1
+                lib.rt_scene_set_tail_flag(sc._h, None)
+
+        threads = [threading.Thread(target=worker, args=(i,), name=f"rt-frame-{i}") for i in range(min(depth, n))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return stats
+
+    def close(self):
+        for sc in self.scenes:
+            sc.close()
+

@@ -507,6 +507,7 @@ struct RtScene {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     rt::DeviceCounters* d_counters = nullptr;
     RtRenderStats stats{};
+    int32_t* tail_flag = nullptr;  // rt_scene_set_tail_flag: set to 1 when a render stops filling the GPU (frame pipelining)
     // wavefront pipeline resources (allocated on first use, reused between renders)
     struct Wavefront {
         uint32_t capacity = 0;
@@ -887,7 +888,10 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
             size_t ev = 0;
             if (fuse && first_round) ev = 2;  // events 0 / 1 bracket the stand-alone prims launch above
             const size_t ev0 = ev;
-            for (uint32_t k = 0; k < check_every; k++) {
+            // near the end of the last group the host looks after every second iteration, so that the tail is seen when it starts
+            const bool near_end = s->tail_flag && t0 + nrep >= T && w.h_ctr->next_sample + 4ull * pool.capacity >= grp.total;
+            const uint32_t check_now = near_end ? std::min<uint32_t>(check_every, 2u) : check_every;
+            for (uint32_t k = 0; k < check_now; k++) {
                 HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 if (split || prims_only) {
                     if (!fuse) RT_LAUNCH_PRIMS_ANY();
@@ -971,6 +975,9 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
                                  double(a[5][k]), double(a[6][k]), double(a[7][k]), double(a[8][k]), double(a[9][k]), hpc[k], (unsigned long long)rngs[k]);
             }
             upper = w.h_ctr->n_in;
+            // every sample of the last group has been started and slots are running empty: from here on this render cannot
+            // fill the GPU any more, the next frame's render (another RtScene, another stream) may start underneath it
+            if (s->tail_flag && t0 + nrep >= T && upper < first) __atomic_store_n(s->tail_flag, 1, __ATOMIC_RELEASE);
             if (upper == 0) break;
         }
 #undef RT_LAUNCH_PRIMS_ANY
@@ -1114,8 +1121,8 @@ uint32_t rt_owned_rows(uint32_t image_height, const RtRenderParams* params) {
     return rt::owned_rows(image_height, params);
 }
 
-int rt_render_device(const RtScene* scene, const RtCameraDesc* camera, const RtRenderParams* params,
-                     double* d_rgba_out, void* stream) {
+static int render_device_impl(const RtScene* scene, const RtCameraDesc* camera, const RtRenderParams* params,
+                              double* d_rgba_out, void* stream) {
     using namespace rt;
     if (!scene || !camera || !params || !d_rgba_out) return set_err(RT_E_INVALID, "rt_render_device: NULL argument");
     if (int v = validate_render_args(camera, params)) return v;
@@ -1150,7 +1157,21 @@ int rt_render_device(const RtScene* scene, const RtCameraDesc* camera, const RtR
     return render_typed<double>(s, *s->f64, *camera, *params, owned, d_rgba_out, st);
 }
 
-int rt_render(const RtScene* scene, const RtCameraDesc* camera, const RtRenderParams* params, double* rgba_out) {
+int rt_render_device(const RtScene* scene, const RtCameraDesc* camera, const RtRenderParams* params,
+                     double* d_rgba_out, void* stream) {
+    int r = render_device_impl(scene, camera, params, d_rgba_out, stream);
+    // whoever waits for this render's tail (rt_scene_set_tail_flag) is released at the latest here, errors included
+    if (scene && scene->tail_flag) __atomic_store_n(scene->tail_flag, 1, __ATOMIC_RELEASE);
+    return r;
+}
+
+int rt_scene_set_tail_flag(RtScene* scene, int32_t* flag) {
+    if (!scene) return rt::set_err(RT_E_INVALID, "rt_scene_set_tail_flag: NULL scene");
+    scene->tail_flag = flag;
+    return RT_OK;
+}
+
+static int render_host_impl(const RtScene* scene, const RtCameraDesc* camera, const RtRenderParams* params, double* rgba_out) {
     using namespace rt;
     if (!scene || !camera || !params || !rgba_out) return set_err(RT_E_INVALID, "rt_render: NULL argument");
     if (int v = validate_render_args(camera, params)) return v;
@@ -1167,6 +1188,12 @@ int rt_render(const RtScene* scene, const RtCameraDesc* camera, const RtRenderPa
     }
     (void)hipFree(d_out);
     return st;
+}
+
+int rt_render(const RtScene* scene, const RtCameraDesc* camera, const RtRenderParams* params, double* rgba_out) {
+    int r = render_host_impl(scene, camera, params, rgba_out);
+    if (scene && scene->tail_flag) __atomic_store_n(scene->tail_flag, 1, __ATOMIC_RELEASE);  // also on the early error returns
+    return r;
 }
 
 // Diagnostic: traces ONE sample on the device and returns its radiance plus a per-bounce record

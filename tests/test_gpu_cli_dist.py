@@ -88,14 +88,15 @@ def test_bench_starts_its_own_ranks():
     no GPU call) and report n_gpus = 2; a launcher whose world size disagrees with --gpus is an error."""
     env = dict(os.environ, RT_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")   # both ranks on cuda:0, gloo
     env.pop("WORLD_SIZE", None)
-    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "c2",
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", "c2",
            "--spp-divisor", "16", "--no-cpu-baseline"]
     r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     res = json.loads(lines[0])
-    assert res["n_gpus"] == 2 and res["steps"] == 1 and res["value"] > 0 and res["scaling"] == "strong"
+    assert res["n_gpus"] == 2 and res["steps"] == 4 and res["value"] > 0 and res["scaling"] == "strong"
+    assert res["config"]["frames_in_flight"] == 3      # multi-GPU ranks pipeline their frames (api.FramePipeline)
     assert "REHEARSAL" in res["config"]["partition"]
     bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "3", "--steps", "1", "--no-cpu-baseline"],
                          cwd=REPO, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)

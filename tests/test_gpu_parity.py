@@ -310,6 +310,78 @@ def test_quantised_bvh_nodes_on_awkward_meshes(dev, tmp_path, monkeypatch, case)
     np.testing.assert_array_equal(frames["1"], frames["0"])
 
 
+def test_frame_pipeline_frames_are_the_single_render_frames(dev):
+    """api.FramePipeline (two device scenes, two host threads, two streams; frame k+1 starts under the tail of frame k,
+    rt_scene_set_tail_flag) must produce, for every frame, exactly the frame one DeviceScene renders on its own — here five
+    frames with different seeds and one with a different row partition, wavefront scheduler with a small pool so that
+    every render has many iterations and a long tail."""
+    import torch
+    hs = api.HostScene(SCENES["light_test"])
+    plist = []
+    for k in range(5):
+        p = hs.params.copy()
+        p.pipeline = api.RT_PIPELINE_WAVEFRONT
+        p.seed = 100 + k
+        plist.append(p)
+    single = api.DeviceScene(hs.desc, 0)
+    want = [single.render(hs.camera, p) for p in plist]
+    device = torch.device("cuda", 0)
+    outs = [torch.zeros((hs.height, hs.width, 4), dtype=torch.float64, device=device) for _ in plist]
+    streams = [torch.cuda.Stream(device) for _ in range(2)]
+    os.environ["RT_WF_POOL"] = "4096"
+    try:
+        pipe = api.FramePipeline(hs.desc, 0, depth=2)
+        stats = pipe.render_frames(hs.camera, plist, [o.data_ptr() for o in outs], [s.cuda_stream for s in streams])
+    finally:
+        del os.environ["RT_WF_POOL"]
+    torch.cuda.synchronize()
+    assert len(stats) == 5 and all(st.samples == hs.width * hs.height * hs.spp for st in stats)
+    for k in range(5):
+        got = outs[k].cpu().numpy()
+        same = (got == want[k]) | (np.isnan(got) & np.isnan(want[k]))
+        assert same.all(), f"frame {k} of the pipeline differs from the single render"
+    # three frames in flight (what bench.py uses on a multi-GPU rank)
+    for o in outs:
+        o.zero_()
+    three = api.FramePipeline(hs.desc, 0, depth=3)
+    three.render_frames(hs.camera, plist, [o.data_ptr() for o in outs], [s.cuda_stream for s in streams] + [torch.cuda.Stream(device).cuda_stream])
+    torch.cuda.synchronize()
+    for k in range(5):
+        got = outs[k].cpu().numpy()
+        assert ((got == want[k]) | (np.isnan(got) & np.isnan(want[k]))).all(), f"frame {k} of the 3-deep pipeline differs"
+    # depth 1 degenerates to one render after the other
+    one = api.FramePipeline(hs.desc, 0, depth=1)
+    one.render_frames(hs.camera, plist[:2], [o.data_ptr() for o in outs[3:5]], [streams[0].cuda_stream])
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(outs[3].cpu().numpy(), want[0])
+    np.testing.assert_array_equal(outs[4].cpu().numpy(), want[1])
+
+
+def test_tail_flag_is_set_by_every_render_and_on_errors(dev):
+    hs = api.HostScene(SCENES["cornell"])
+    scene = api.DeviceScene(hs.desc, 0)
+    lib = scene._lib
+    flag = C.c_int32(0)
+    assert lib.rt_scene_set_tail_flag(scene._h, C.addressof(flag)) == api.RT_OK
+    for pipeline in (api.RT_PIPELINE_WAVEFRONT, api.RT_PIPELINE_MEGAKERNEL):
+        p = hs.params.copy()
+        p.pipeline = pipeline
+        flag.value = 0
+        scene.render(hs.camera, p)
+        assert flag.value == 1
+    bad = hs.params.copy()
+    bad.sqrt_spt = 0
+    flag.value = 0
+    with pytest.raises(api.RtError):
+        scene.render(hs.camera, bad)
+    assert flag.value == 1                      # a waiting frame is released even when the render fails
+    assert lib.rt_scene_set_tail_flag(scene._h, None) == api.RT_OK
+    flag.value = 0
+    scene.render(hs.camera, hs.params)
+    assert flag.value == 0                      # cleared: the library no longer writes to it
+    assert lib.rt_scene_set_tail_flag(None, None) == api.RT_E_INVALID
+
+
 def test_stats_counters_and_collect_flag(dev):
     hs = api.HostScene(SCENES["light_test"])
     scene = api.DeviceScene(hs.desc, 0)
