@@ -359,6 +359,9 @@ def main():
     roofline = None
     if counters is not None and counters.rays > 0 and kstats:
         roofline = make_roofline(api, counters, kstats, a, rows * hs.width, elapsed / a.steps * 1e3)
+        if roofline and depth > 1:
+            roofline["note"] += (f"  {depth} frames are in flight on this rank: a kernel's HIP-event duration includes the time it shares the "
+                                 "GPU with the neighbouring frames' tail launches; the N = 1 line has the undisturbed figures.")
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
