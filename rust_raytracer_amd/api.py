@@ -401,8 +401,9 @@ class FramePipeline:
     produces on its own (same kernels, same per-sample RNG keys): tests/test_gpu_parity.py::test_frame_pipeline_*.
     """
 
-    def __init__(self, desc, device: int = 0, depth: int = 2):
-        self.scenes = [DeviceScene(desc, device) for _ in range(max(1, depth))]
+    def __init__(self, desc, device: int = 0, depth: int = 2, scenes=None):
+        """`scenes`: ready-made device scenes instead of `depth` new ones (the CPU tests of the ordering logic pass stand-ins)."""
+        self.scenes = list(scenes) if scenes is not None else [DeviceScene(desc, device) for _ in range(max(1, depth))]
         self.device = device
 
     @property
