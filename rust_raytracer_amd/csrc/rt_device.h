@@ -153,6 +153,13 @@ template <typename R> RT_DEV V3<R> random_cosine(Rng& g) {  // vec4.rs:50-61
     return mk<R>(x, y, z);
 }
 
+// Inverse trigonometric functions of the UV maps (sphere.rs:30-38, sky.rs:40-46), kept OUT of line on purpose: inlined, hipcc
+// materialises the thirteen f64 polynomial coefficients of acos (and atan2's) in VGPR pairs at the top of the kernel - they are
+// loop-invariant - and keeps them live through the whole of k_wf_shade, 26 registers of a kernel whose occupancy is set by its
+// registers, for code that only sphere and sky hits execute.  A call costs those hits a few dozen cycles.
+template <typename R> __attribute__((noinline)) RT_DEV R uv_acos(R x) { return acos(x); }
+template <typename R> __attribute__((noinline)) RT_DEV R uv_atan2(R y, R x) { return atan2(y, x); }
+
 // ------------------------------------------------------------------ ray.rs
 template <typename R>
 struct Ray {
@@ -670,8 +677,8 @@ RT_DEV HitInfo<R> resolve_hit(const SceneView<R>& sc, const Ray<R>& wray, const 
             outward = (h.pos - ld3(s.center)) / s.radius;
             h.material = s.material;
             if (sc.materials[s.material].needs_uv) {
-                R theta = acos(outward.y);
-                R phi = atan2(-outward.z, outward.x) + pi<R>();
+                R theta = uv_acos(outward.y);
+                R phi = uv_atan2(-outward.z, outward.x) + pi<R>();
                 if constexpr (TEX) {
                     tangent = mk<R>(-outward.z, R(0), -outward.x);  // sphere.rs:83-84
                     bitangent = cross(outward, tangent);
@@ -731,7 +738,7 @@ RT_DEV HitInfo<R> resolve_hit(const SceneView<R>& sc, const Ray<R>& wray, const 
             outward = -unit_dir;
             h.material = op.arg;
             if (sc.materials[op.arg].needs_uv) {
-                h.u = atan2(unit_dir.x, unit_dir.z) / (R(2) * pi<R>()) + R(0.5);
+                h.u = uv_atan2(unit_dir.x, unit_dir.z) / (R(2) * pi<R>()) + R(0.5);
                 h.v = dot(unit_dir, mk<R>(0, 1, 0)) / R(2) + R(0.5);
             }
             break;

@@ -905,12 +905,13 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
 // ---------------------------------------------------------------------------------------------
 // Shade: one path vertex per lane (camera.rs:295-331), regeneration and queue compaction.
 // ---------------------------------------------------------------------------------------------
-// Waves per SIMD asked of the register allocator for k_wf_shade: 3 (<= 168 VGPRs) for the lean variant, which fits
-// without scratch since the store addresses are re-read (see the write-back) — the kernel is latency-bound and ran at
-// 2 waves (188-197 VGPRs) before.  The texture-interpreter and the fused variants need 205-256 registers: no cap
-// (it would cost them 70-330 B of scratch per lane).
+// Waves per SIMD asked of the register allocator for k_wf_shade: 4 (<= 128 VGPRs) for the lean variant.  It needs 106 since
+// the inverse trigonometric functions of the UV maps are called out of line (uv_acos / uv_atan2 in rt_device.h: inlined, their
+// polynomial coefficients sat in 50 VGPRs for the whole kernel); 166 and 3 waves before that, 188-197 and 2 waves in round 1.
+// 5 waves (96 VGPRs + 16 B of scratch) are slower.  The fused variant needs 125-130 registers, the texture-interpreter
+// variants 174-189: no cap for them.
 #ifndef RT_SHADE_WAVES
-#define RT_SHADE_WAVES 3
+#define RT_SHADE_WAVES 4
 #endif
 #define RT_SHADE_BOUNDS __launch_bounds__(256, (TEX || FUSE) ? 1 : RT_SHADE_WAVES)
 // FUSE: the scene has the split intersect (one mesh op, or none): the primitive program (prims_search) runs HERE on
