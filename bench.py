@@ -161,19 +161,31 @@ def make_roofline(api, counters, kstats, a, owned_pixels, ms_per_step):
                 traffic = traffic / n_launch
         except Exception:
             traffic = None
+    # second ceiling (these kernels run f64 arithmetic on most issue slots): share of the SIMD cycles in which a VALU instruction is
+    # issued = profiled wave-level VALU instruction count x 4 clk / (this run's kernel time x 1024 SIMDs x 2.4 GHz); a lower
+    # bound, f64 division / sqrt / reciprocal steps issue at a quarter of that rate
+    valu_share = None
+    try:
+        insts = json.load(open(tpath)).get(f"{a.workload}_{a.precision}_{name.split()[0]}_valu_insts_per_step")
+        if insts:
+            valu_share = insts * 4.0 / (ms_step * 1e-3 * 2.4e9 * 1024)
+    except Exception:
+        valu_share = None
     cache_resident = achieved > HBM_PEAK_GBS
     out = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "traffic": traffic,
         # what the memory side really moved for this kernel (counter bytes of the profiled run / this run's kernel time)
         "frac_traffic": None if traffic is None else traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "valu_issue_share": valu_share,
         "kernel": name,
         "note": ("algorithmic bytes / kernel time (HIP events).  " +
                  ("The algorithmic rate of this kernel is ABOVE the HBM peak because part of its bytes is served by L1 / L2 and the 256 MB Infinity Cache "
                   "(87 MB of BVH nodes and triangle records): `frac` is the measured fabric-side fraction (`frac_traffic`), see `frac_basis`.  "
                   if cache_resident else "") +
                  "`traffic` = rocprofv3 counter bytes of the same kernel per launch (2 x FETCH_SIZE + WRITE_SIZE, fabric side, "
-                 "calibration in profiles/r01/fetch_size_calibration.txt), from profiles/traffic.json when this workload was profiled."),
+                 "calibration in profiles/r01/fetch_size_calibration.txt), from profiles/traffic.json when this workload was profiled.  "
+                 "`valu_issue_share`: VALU instructions of the profiled run x 4 clk / (kernel time x SIMDs x clock), the kernel's other ceiling."),
         "dominant_kernel_share_of_step": ms_step / ms_per_step,
         "kernel_ms_avg": avg_ms, "launches_per_step": n_launch, "algorithmic_bytes_per_launch": nbytes,
         "kernel_ms_per_step": ms_step,
