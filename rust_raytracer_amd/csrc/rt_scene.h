@@ -115,7 +115,7 @@ struct alignas(128) BvhNode4f {
 // The same node in 64 B (four 16-B loads instead of seven): child boxes as 8-bit grid coordinates relative to a
 // per-node origin and per-axis power-of-two cell size (the compressed wide BVH node of Ylitie, Karras, Laine 2017,
 // 4-wide here).  A wave whose lanes read 64 different nodes pays one L1 cycle per lane and LOAD INSTRUCTION
-// (tools/micro_l1.hip: 64 clk per 16-B wave load, 449 clk per visit of a 7-load record, 291 of a 4-load one), which is
+// (tools/ubench/micro_l1.hip: 64 clk per 16-B wave load, 449 clk per visit of a 7-load record, 291 of a 4-load one), which is
 // what bounds k_wf_mesh.  Decoded plane = org + q * cell, q_lo rounded down and q_hi up on the grid from the boxes
 // of BvhNode4f (padding included), so the quantised box contains the padded f32 box; the decode's own rounding
 // (one fma per plane) stays inside that padding (see the node builder in rt_kernels.hip).

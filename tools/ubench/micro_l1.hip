@@ -2,7 +2,7 @@
 // random 128-byte record per lane (64 lanes = 64 different lines), as a dependent chain like a BVH descent?
 //   time per record visit flat in L        -> latency-bound: a smaller node buys nothing
 //   time per record visit growing with L   -> the L1's per-line request rate binds: a 64-byte node (4 loads) pays
-// Build: hipcc --offload-arch=gfx950 -O3 -o /tmp/micro_l1 tools/micro_l1.hip && /tmp/micro_l1 [table MiB]   (on the GPU box).
+// Build: hipcc --offload-arch=gfx950 -O3 -o /tmp/micro_l1 tools/ubench/micro_l1.hip && /tmp/micro_l1 [table MiB]   (on the GPU box).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
