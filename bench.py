@@ -41,6 +41,9 @@ WORKLOADS = {
     # the reference's built-in default scene (main.rs without a scene file: 440-sphere field in its object-BVH, Suzanne,
     # sun + sky) at the size of samples/sample0.png; BASELINE config C1 is this scene at 400x266 @64spp on the CPU
     "c1": (["-w=1200", "-s=256", "-t=4"], "default scene (golden_monkey.rs) 1200x800 @256spp, 440 spheres in an object BVH + Suzanne 15.7k tri"),
+    # rows f-3 / f-4 of SURVEY section 8: more than one mesh instance in `world`, and constant-density volumes
+    "two_meshes": (["tests/scenes/two_meshes", "-w=800", "-s=256"], "tests/scenes/two_meshes 800x800 @256spp, two transformed mesh instances (2 x 967 tri)"),
+    "smoke": (["scenes/cornell_smoke", "-w=800", "-s=256"], "scenes/cornell_smoke 800x800 @256spp, two constant-density volumes bounded by boxes"),
 }
 
 
@@ -66,6 +69,38 @@ def cpu_model() -> str:
     return "unknown"
 
 
+def physical_cores():
+    """One hardware thread per physical core of the CPUs this process may run on (SMT siblings dropped)."""
+    allowed = sorted(os.sched_getaffinity(0))
+    seen, cores = set(), []
+    for cpu in allowed:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list") as f:
+                key = f.read().strip()
+        except OSError:
+            key = str(cpu)
+        if key not in seen:
+            seen.add(key)
+            cores.append(cpu)
+    return cores
+
+
+def _oracle_rows(hs, p, stride):
+    """The oracle on an unbiased ROW subset (every `stride`-th row), as two disjoint interleaved halves timed separately."""
+    from oracle import pyoracle
+
+    halves = []
+    tot = {"samples": 0, "seconds": 0.0, "rays": 0, "nodes": 0, "tris": 0}
+    for part in (stride // 4, stride // 4 + stride // 2):
+        q = p.copy()
+        q.band_rows, q.n_parts, q.part = 1, stride, part
+        _, st = pyoracle.render(hs.desc, hs.camera, q)
+        halves.append(st.samples / st.seconds / 1e6)
+        tot["samples"] += st.samples; tot["seconds"] += st.seconds
+        tot["rays"] += st.rays; tot["nodes"] += st.node_tests; tot["tris"] += st.tri_tests
+    return halves, tot
+
+
 def cpu_baseline(workload: str, seed: int):
     """Times the CPU oracle on a bounded sample of the same workload (rank 0, N=1 only).
 
@@ -73,9 +108,12 @@ def cpu_baseline(workload: str, seed: int):
     strata, so every pixel gets the workload's spp), on an unbiased ROW subset of the frame (every
     `stride`-th row, not a crop — BASELINE.md section 3 plans 1/16 of the rows, which is > 60 s of CPU work at
     C4; the sample here is sized for ~20 s).  The subset is rendered as TWO disjoint interleaved halves
-    that are timed separately: their spread is the stated variance of the estimate."""
+    that are timed separately: their spread is the stated variance of the estimate.
+
+    `all_cores` (workloads whose spp allows it): the same rows with the samples spread over as many replicas (= OS
+    threads, src/config.rs:154-155: spp = T * floor(sqrt(s / T))^2) as the host has physical cores for, at the SAME spp
+    (-t=40: 40 x 5 x 5 = 1000), pinned to one hardware thread per physical core: what this CPU can really do."""
     from rust_raytracer_amd import api
-    from oracle import pyoracle
 
     args, _ = WORKLOADS[workload]
     hs = api.HostScene(args + [f"--seed={seed}"])
@@ -86,35 +124,79 @@ def cpu_baseline(workload: str, seed: int):
     per_row = hs.width * p.sqrt_spt * p.sqrt_spt * threads
     n_rows = max(2, int(round(target_samples / per_row)))
     stride = max(2, hs.height // n_rows)
-    halves = []
-    tot_samples = tot_rays = tot_nodes = tot_tris = 0
-    tot_seconds = 0.0
-    for part in (stride // 4, stride // 4 + stride // 2):
-        q = p.copy()
-        q.band_rows, q.n_parts, q.part = 1, stride, part
-        _, st = pyoracle.render(hs.desc, hs.camera, q)
-        halves.append(st.samples / st.seconds / 1e6)
-        tot_samples += st.samples; tot_seconds += st.seconds
-        tot_rays += st.rays; tot_nodes += st.node_tests; tot_tris += st.tri_tests
-    value = tot_samples / tot_seconds / 1e6
-    rows = tot_samples // (hs.width * p.sqrt_spt * p.sqrt_spt * threads)
-    return {
+    halves, tot = _oracle_rows(hs, p, stride)
+    value = tot["samples"] / tot["seconds"] / 1e6
+    rows = tot["samples"] // per_row
+    out = {
         "value": value,
         "unit": "Msamples/s",
         "cores": min(threads, avail),
         "kind": "port",
         "sample": f"{rows} of {hs.height} rows (every {stride}th, two interleaved halves) x {hs.width} px x {threads} replicas "
-                  f"(= OS threads, the workload's -t) x {p.sqrt_spt * p.sqrt_spt} strata = {tot_samples} samples in "
-                  f"{tot_seconds:.1f}s (octree build excluded); halves {halves[0]:.3f} / {halves[1]:.3f} Msamples/s "
+                  f"(= OS threads, the workload's -t) x {p.sqrt_spt * p.sqrt_spt} strata = {tot['samples']} samples in "
+                  f"{tot['seconds']:.1f}s (octree build excluded); halves {halves[0]:.3f} / {halves[1]:.3f} Msamples/s "
                   f"(spread {abs(halves[0] - halves[1]) / value:.1%}); oracle/liboracle.so -O3 x86-64-v3, f64, recursive, "
                   f"reference octree; keyed per-sample RNG (the reference's is one sequential stream per thread)",
         "cpu_model": cpu_model(),
         "host_cores_available": avail,
         "halves": halves,
-        "rays_per_sample": tot_rays / max(tot_samples, 1),
-        "node_tests_per_ray": tot_nodes / max(tot_rays, 1),
-        "tri_tests_per_ray": tot_tris / max(tot_rays, 1),
+        "rays_per_sample": tot["rays"] / max(tot["samples"], 1),
+        "node_tests_per_ray": tot["nodes"] / max(tot["rays"], 1),
+        "tri_tests_per_ray": tot["tris"] / max(tot["rays"], 1),
     }
+    # the same spp on more replicas: T' = the largest T' <= physical cores with T' * floor(sqrt(s / T'))^2 == spp
+    cores = physical_cores()
+    spp = threads * p.sqrt_spt * p.sqrt_spt
+    best = None
+    for t2 in range(min(len(cores), 128), threads, -1):
+        s2 = int((spp // t2) ** 0.5)
+        if s2 >= 1 and t2 * s2 * s2 == spp:
+            best = (t2, s2)
+            break
+    if best:
+        t2, s2 = best
+        q = p.copy()
+        q.thread_count, q.sqrt_spt = t2, s2
+        saved = os.sched_getaffinity(0)
+        try:
+            os.sched_setaffinity(0, set(cores))
+            halves2, tot2 = _oracle_rows(hs, q, stride)
+        finally:
+            os.sched_setaffinity(0, saved)
+        v2 = tot2["samples"] / tot2["seconds"] / 1e6
+        out["all_cores"] = {
+            "value": v2, "unit": "Msamples/s", "cores": t2, "physical_cores_available": len(cores),
+            "sample": f"the same {rows} rows at the same spp as -t={t2} x {s2}x{s2} strata ({t2} OS threads on {len(cores)} physical cores, one "
+                      f"hardware thread per core): {tot2['samples']} samples in {tot2['seconds']:.1f}s; halves {halves2[0]:.3f} / {halves2[1]:.3f}",
+            "halves": halves2,
+        }
+    return out
+
+
+# Second ceiling of these kernels: wave-level VALU instructions per second.  A wave64 instruction occupies a SIMD-32 for 4 clk
+# (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'): 1024 SIMDs x 2.4 GHz / 4 = 614.4 G instructions/s.  f64 divisions,
+# square roots and reciprocals issue at a quarter of that rate, so the share computed from the instruction COUNT is a lower bound.
+VALU_PEAK_GINST = 1024 * 2.4 / 4.0
+
+
+def profiled_entry(workload: str, precision: str, launches: float):
+    """Counter figures of this workload from profiles/traffic.json (tools/make_traffic.py), or (None, reason) when the workload
+    was not profiled or the profile is stale: taken on other library sources, or at another number of launches per step."""
+    try:
+        entry = json.load(open(os.path.join(REPO, "profiles", "traffic.json"))).get("entries", {}).get(f"{workload}_{precision}")
+    except Exception:
+        entry = None
+    if not entry:
+        return None, "this workload has no rocprofv3 counter profile under profiles/"
+    try:
+        digest = open(os.path.join(REPO, "rust_raytracer_amd", "librt_mi355.so.srchash")).read().strip()
+    except OSError:
+        digest = ""
+    if entry.get("lib_digest") != digest:
+        return None, f"stale profile ({entry.get('profile')}): the library sources have changed since it was taken"
+    if abs(float(entry.get("launches_per_step", -1)) - launches) > 0.5:
+        return None, f"stale profile ({entry.get('profile')}): {entry.get('launches_per_step')} launches per step then, {launches} now"
+    return entry, None
 
 
 def make_roofline(api, counters, kstats, a, owned_pixels, ms_per_step):
@@ -122,13 +204,17 @@ def make_roofline(api, counters, kstats, a, owned_pixels, ms_per_step):
 
     Algorithmic bytes are counted by the kernels themselves in the counter-collecting warm-up step (deterministic
     for a given seed / config) and divided by the launches per step; durations are HIP-event times on the render
-    stream, summed per kernel by the library (RtRenderStats).  All kernels here are bound by memory traffic or by
-    latency, none by matrix throughput: bound = "hbm".
-      k_wf_mesh / k_wf_intersect / k_megakernel: BVH nodes fetched x node size + triangle tests x record size
-                                                 (+ path state of the rays handled)
-      k_wf_shade / k_wf_prims:                   path-state bytes read + written per ray
-    A kernel whose algorithmic bytes per second exceed the HBM peak is running out of L2 / Infinity Cache
-    (small BVH): `frac` is then null, never > 1."""
+    stream, summed per kernel by the library (RtRenderStats).  No kernel here is a dense contraction (no MFMA); each is
+    priced against BOTH ceilings it can meet and `bound` names the one it is closer to:
+      hbm    bytes / kernel time / 8 TB/s.  Algorithmic bytes:
+               k_wf_mesh / k_wf_intersect / k_megakernel: BVH nodes fetched x node size + triangle tests x record size
+                                                          (+ path state of the rays handled)
+               k_wf_shade / k_wf_prims:                   path-state bytes read + written per ray
+             and, when this workload has a current counter profile, the fabric-side bytes rocprofv3 measured (`traffic`).
+             A kernel whose algorithmic rate exceeds the HBM peak is running out of L2 / Infinity Cache: its fraction is
+             then the measured one, never > 1.
+      valu   wave-level VALU instructions (SQ_INSTS_VALU of the profile) / kernel time / 614.4 G/s: the f64 arithmetic
+             of the path tracer (a lower bound of the issue time: quarter-rate f64 division / sqrt steps count once)."""
     n = len(kstats)
     mean = lambda k: sum(x[k] for x in kstats) / n
     launches = mean("launches")
@@ -138,7 +224,7 @@ def make_roofline(api, counters, kstats, a, owned_pixels, ms_per_step):
         cands = {"k_megakernel": (mean("all"), bvh_bytes + counters.mesh_rays * counters.bytes_attr + owned_pixels * 32, 1.0)}
     else:
         cands = {
-            "k_wf_mesh (BVH traversal; k_wf_intersect for scenes with volumes or != 1 mesh)":
+            "k_wf_mesh (BVH traversal; k_wf_intersect for scenes the split kernels do not cover)":
                 (mean("traversal"), bvh_bytes + counters.mesh_rays * counters.bytes_state, launches),
             "k_wf_shade (scatter, pdf, regeneration, compaction)":
                 (mean("shade"), counters.rays * counters.bytes_state_shade + counters.samples * 24, launches),
@@ -148,44 +234,45 @@ def make_roofline(api, counters, kstats, a, owned_pixels, ms_per_step):
     name, (ms_step, nbytes_step, n_launch) = max(cands.items(), key=lambda kv: kv[1][0])
     if ms_step <= 0:
         return None
+    short = name.split()[0]
     avg_ms = ms_step / n_launch
     nbytes = nbytes_step / n_launch
-    achieved = nbytes / (avg_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(REPO, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            key = f"{a.workload}_{a.precision}_{name.split()[0]}_per_step"
-            traffic = json.load(open(tpath)).get(key)
-            if traffic is not None:
-                traffic = traffic / n_launch
-        except Exception:
-            traffic = None
-    # second ceiling (these kernels run f64 arithmetic on most issue slots): share of the SIMD cycles in which a VALU instruction is
-    # issued = profiled wave-level VALU instruction count x 4 clk / (this run's kernel time x 1024 SIMDs x 2.4 GHz); a lower
-    # bound, f64 division / sqrt / reciprocal steps issue at a quarter of that rate
-    valu_share = None
-    try:
-        insts = json.load(open(tpath)).get(f"{a.workload}_{a.precision}_{name.split()[0]}_valu_insts_per_step")
-        if insts:
-            valu_share = insts * 4.0 / (ms_step * 1e-3 * 2.4e9 * 1024)
-    except Exception:
-        valu_share = None
-    cache_resident = achieved > HBM_PEAK_GBS
+    alg_rate = nbytes / (avg_ms * 1e-3) / 1e9
+    entry, why_not = profiled_entry(a.workload, a.precision, 1.0 if mega else launches)
+    kprof = (entry or {}).get("kernels", {}).get(short) if entry else None
+    traffic = kprof["bytes_per_step"] / n_launch if kprof else None
+    frac_traffic = None if traffic is None else traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    valu_rate = valu_share = None
+    if kprof and kprof.get("valu_insts_per_step"):
+        valu_rate = kprof["valu_insts_per_step"] / (ms_step * 1e-3) / 1e9
+        valu_share = valu_rate / VALU_PEAK_GINST
+    cache_resident = alg_rate > HBM_PEAK_GBS
+    if not cache_resident:
+        hbm_frac, hbm_basis = alg_rate / HBM_PEAK_GBS, "algorithmic bytes / kernel time / HBM peak"
+    else:
+        hbm_frac = frac_traffic
+        hbm_basis = ("counter bytes (2 x FETCH_SIZE + WRITE_SIZE, profiles/traffic.json) / kernel time / HBM peak: the algorithmic rate "
+                     f"({alg_rate:.0f} GB/s) exceeds the HBM peak, L1 / L2 / Infinity Cache serve part of it")
+    valu_bound = valu_share is not None and (hbm_frac is None or valu_share > hbm_frac)
     out = {
-        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "valu" if valu_bound else "hbm",
+        "achieved": valu_rate if valu_bound else alg_rate,
+        "peak": VALU_PEAK_GINST if valu_bound else HBM_PEAK_GBS,
+        "unit": "G wave-instructions/s" if valu_bound else "GB/s",
+        "frac": valu_share if valu_bound else hbm_frac,
+        "frac_basis": ("VALU instructions of the profiled run (SQ_INSTS_VALU, profiles/traffic.json) / this run's kernel time / (1024 SIMDs x 2.4 GHz / 4 clk): "
+                       "above this kernel's HBM fraction, so vector issue is the nearer ceiling") if valu_bound else hbm_basis,
         "traffic": traffic,
-        # what the memory side really moved for this kernel (counter bytes of the profiled run / this run's kernel time)
-        "frac_traffic": None if traffic is None else traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "valu_issue_share": valu_share,
+        "hbm": {"achieved": alg_rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac, "frac_basis": hbm_basis,
+                "traffic": traffic, "frac_traffic": frac_traffic},
+        "valu": {"achieved": valu_rate, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": valu_share},
+        "profile": (entry or {}).get("profile") if kprof else None,
+        "profile_note": why_not if not kprof else None,
         "kernel": name,
-        "note": ("algorithmic bytes / kernel time (HIP events).  " +
-                 ("The algorithmic rate of this kernel is ABOVE the HBM peak because part of its bytes is served by L1 / L2 and the 256 MB Infinity Cache "
-                  "(87 MB of BVH nodes and triangle records): `frac` is the measured fabric-side fraction (`frac_traffic`), see `frac_basis`.  "
-                  if cache_resident else "") +
-                 "`traffic` = rocprofv3 counter bytes of the same kernel per launch (2 x FETCH_SIZE + WRITE_SIZE, fabric side, "
-                 "calibration in profiles/r01/fetch_size_calibration.txt), from profiles/traffic.json when this workload was profiled.  "
-                 "`valu_issue_share`: VALU instructions of the profiled run x 4 clk / (kernel time x SIMDs x clock), the kernel's other ceiling."),
+        "note": ("HIP-event kernel time on the render stream; algorithmic bytes counted by the kernels.  `traffic` = rocprofv3 counter bytes of the same "
+                 "kernel per launch (2 x FETCH_SIZE + WRITE_SIZE, fabric side: Infinity-Cache hits are counted; calibration in "
+                 "profiles/r01/fetch_size_calibration.txt), present only while profiles/traffic.json holds a profile of THIS library build at THIS "
+                 "number of launches per step (`profile_note` says why not)."),
         "dominant_kernel_share_of_step": ms_step / ms_per_step,
         "kernel_ms_avg": avg_ms, "launches_per_step": n_launch, "algorithmic_bytes_per_launch": nbytes,
         "kernel_ms_per_step": ms_step,
@@ -197,15 +284,18 @@ def make_roofline(api, counters, kstats, a, owned_pixels, ms_per_step):
         "bytes_node": counters.bytes_node, "bytes_tri": counters.bytes_tri,
         "bytes_state_shade": counters.bytes_state_shade, "bytes_state_prims": counters.bytes_state_prims,
     }
-    # `frac`: algorithmic rate / peak.  When the algorithmic rate is ABOVE the peak (caches serve part of the bytes) that ratio
-    # is not a statement about HBM: the measured fabric-side fraction is given instead and `frac_basis` says so.
-    if not cache_resident:
-        out["frac"], out["frac_basis"] = achieved / HBM_PEAK_GBS, "algorithmic bytes / kernel time / HBM peak"
-    else:
-        out["frac"] = out["frac_traffic"]
-        out["frac_basis"] = ("counter bytes (2 x FETCH_SIZE + WRITE_SIZE, profiles/traffic.json) / kernel time / HBM peak: the algorithmic rate "
-                             f"({achieved:.0f} GB/s) exceeds the HBM peak, L1 / L2 / Infinity Cache serve part of it")
-    if name.startswith("k_wf_mesh") and counters.node_visits:
+    if entry and not mega:  # every profiled kernel of this workload against both ceilings
+        per = {}
+        for k, (ms_k, nb_k, nl_k) in cands.items():
+            kp = entry["kernels"].get(k.split()[0])
+            if not kp or ms_k <= 0:
+                continue
+            per[k.split()[0]] = {"ms_per_step": ms_k, "hbm_frac_algorithmic": nb_k / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "hbm_frac_traffic": kp["bytes_per_step"] / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "write_over_algorithmic": None,
+                                 "valu_issue_share": (kp["valu_insts_per_step"] / (ms_k * 1e-3) / 1e9 / VALU_PEAK_GINST) if kp.get("valu_insts_per_step") else None}
+        out["kernels"] = per
+    if short == "k_wf_mesh" and counters.node_visits:
         # the memory system's own limit for this access pattern (dependent fetches of random 128-B lines):
         # tools/ubench/gather_lines on the same chip, profiles/r01/ubench_gather_lines.txt
         out["line_requests_per_s"] = (counters.node_visits * -(-counters.bytes_node // 128) + counters.tri_tests * counters.bytes_tri / 128.0) / n_launch / (avg_ms * 1e-3)
@@ -262,8 +352,9 @@ def main():
     ap.add_argument("--spp-divisor", type=int, default=1, help="debug: render spp/divisor (result is then labelled reduced)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="device scenes of the frame pipeline (api.FramePipeline): 1 = the timed frames strictly one after the other; "
-                         "default 1 on one GPU, 3 with --gpus > 1 (frame k+1 starts under the tail of frame k)")
+                    help="device scenes of the frame pipeline (api.FramePipeline): 1 (default, every N) = the timed frames strictly one after "
+                         "the other, so that the N = 1 and N > 1 lines measure the same thing; 3 = frame k+1 starts under the tail of frame k "
+                         "(throughput of a frame SEQUENCE: the line then says value_basis = pipelined)")
     ap.add_argument("--no-overlap", action="store_true", help="same as --frames-in-flight 1")
     ap.add_argument("--save-png", default="")
     a = ap.parse_args()
@@ -311,14 +402,11 @@ def main():
         s = int([x for x in args if x.startswith("-s=")][0][3:]) // a.spp_divisor
         args = [x for x in args if not x.startswith("-s=")] + [f"-s={s}"]
     hs = api.HostScene(args + [f"--seed={a.seed}", f"--precision={a.precision}", f"--pipeline={a.pipeline}"])
-    # The K timed steps are K frames of the same job.  On one GPU they are rendered one after the other.  A rank of a multi-GPU
-    # run renders 1/N of the rows, and the end of such a render — the last, longest paths: 20 of its 44 iterations at N = 8 — is
-    # a chain of small latency-bound launches that costs 10-14 % of the share (tools/gpu_partscale.py).  There the frames go
-    # through api.FramePipeline: three device scenes (three pools, three streams, one host thread each), frame k+1 starts as
-    # soon as frame k has entered its tail (rt_scene_set_tail_flag).  Every frame is rendered completely and gathered inside
-    # the timed region; only the tails overlap the next frame's start (measured on a 1/8 share: 173 -> 166 ms per frame,
-    # tools/gpu_pipeline_probe.py; nothing to gain on a whole frame, where the tail is 2 %).
-    depth = a.frames_in_flight if a.frames_in_flight > 0 else (3 if world > 1 else 1)
+    # The K timed steps are K frames of the same job, rendered strictly one after the other at every N (depth 1), so that the
+    # N = 1 and N > 1 lines measure the same thing.  --frames-in-flight 3 is the opt-in throughput mode for frame SEQUENCES on a
+    # multi-GPU rank (api.FramePipeline: frame k+1 starts under the tail of frame k, rt_scene_set_tail_flag; measured on a 1/8
+    # share of the headline frame: 173 -> 166 ms per frame, tools/gpu_pipeline_probe.py); the line then says so in `value_basis`.
+    depth = a.frames_in_flight if a.frames_in_flight > 0 else 1
     if a.no_overlap or a.steps < 2:
         depth = 1
     pipe = api.FramePipeline(hs.desc, local_rank, depth)  # BVH build + upload: resident before timing
@@ -394,8 +482,11 @@ def main():
                                     + (" [REHEARSAL: all ranks on one device, gloo]" if one_device else "")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        line["value_basis"] = "single frames, one after the other" if depth == 1 else f"pipelined sequence, {depth} frames in flight"
         if cpu:
             line["speedup_vs_cpu_baseline"] = value / cpu["value"]
+            if cpu.get("all_cores"):
+                line["speedup_vs_cpu_all_cores"] = value / cpu["all_cores"]["value"]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,5 +1,5 @@
 /*
- * rt_detmath.h — deterministic sin/cos/log for the sampling routines.
+ * rt_detmath.h — deterministic sin/cos/log for the sampling routines, acos/atan2 for the UV maps.
  *
  * The reference calls Rust's f64::sin / cos / ln (src/vec4.rs:50-61, src/object/sphere.rs:131-145,
  * rand_distr's normal sampler), i.e. whatever libm the platform has: results differ in the last
@@ -12,7 +12,12 @@
  * and hipcc on gfx950.  Accuracy is ~1 ulp (tests/test_detmath.py), i.e. as good as any libm the
  * reference may have run on.  Used by oracle/oracle.cpp and by the f64 kernels.
  *
- * Domain: det_sincos for |x| <= 64 (callers pass [0, 2 pi)); det_log for normal x > 0.
+ * Domain: det_sincos for |x| <= 64 (callers pass [0, 2 pi)); det_log for normal x > 0;
+ * det_atan / det_atan2 / det_acos: every input (the case analysis of the classic libm algorithms:
+ * zeros, infinities and NaN come out as C's atan2 / acos define them).  They additionally use the
+ * IEEE square root, which is correctly rounded on both sides.  The sphere and sky UV maps
+ * (src/object/sphere.rs:69-75, src/object/sky.rs:40-46) feed texel lookups and checker parities:
+ * a one-ulp difference in u can flip a whole texel, so both sides must share these bits too.
  */
 #ifndef RT_DETMATH_H
 #define RT_DETMATH_H
@@ -98,6 +103,139 @@ RT_DM_HD double det_log(double x) {
     double lm = 2.0 * (s + (s * z) * p);
     double ef = (double)e;
     return ef * ln2_hi + (ef * ln2_lo + lm);
+}
+
+/* atan(x): reduction to |t| < 7/16 around the break points 0.5, 1, 1.5, inf (atan x = atan c + atan((x - c) / (1 + c x)),
+ * the four atan c as hi + lo pairs), odd minimax polynomial of degree 23 in two interleaved Horner chains. */
+RT_DM_HD double det_atan(double x) {
+    const double hi0 = 4.63647609000806093515e-01, lo0 = 2.26987774529616870924e-17; /* atan 0.5 */
+    const double hi1 = 7.85398163397448278999e-01, lo1 = 3.06161699786838301793e-17; /* atan 1   */
+    const double hi2 = 9.82793723247329054082e-01, lo2 = 1.39033110312309984516e-17; /* atan 1.5 */
+    const double hi3 = 1.57079632679489655800e+00, lo3 = 6.12323399573676603587e-17; /* atan inf */
+    if (x != x) return x + x;
+    uint64_t bits;
+    memcpy(&bits, &x, sizeof bits);
+    const int neg = (int)(bits >> 63);
+    double a = neg ? -x : x;
+    double hi = 0.0, lo = 0.0, t;
+    int reduced = 1;
+    if (a >= 7.378697629483820646e19) { /* 2^66: atan = +-pi/2 to the last bit */
+        double r = hi3 + lo3;
+        return neg ? -r : r;
+    }
+    if (a < 0.4375) {
+        if (a < 1.862645149230957e-09) return x; /* 2^-29 */
+        t = x;
+        reduced = 0;
+    } else if (a < 0.6875) {
+        t = (2.0 * a - 1.0) / (2.0 + a); hi = hi0; lo = lo0;
+    } else if (a < 1.1875) {
+        t = (a - 1.0) / (a + 1.0); hi = hi1; lo = lo1;
+    } else if (a < 2.4375) {
+        t = (a - 1.5) / (1.0 + 1.5 * a); hi = hi2; lo = lo2;
+    } else {
+        t = -1.0 / a; hi = hi3; lo = lo3;
+    }
+    double z = t * t;
+    double w = z * z;
+    double s1 = 1.62858201153657823623e-02;
+    s1 = 4.97687799461593236017e-02 + w * s1;
+    s1 = 6.66107313738753120669e-02 + w * s1;
+    s1 = 9.09088713343650656196e-02 + w * s1;
+    s1 = 1.42857142725034663711e-01 + w * s1;
+    s1 = 3.33333333333329318027e-01 + w * s1;
+    s1 = z * s1;
+    double s2 = -3.65315727442169155270e-02;
+    s2 = -5.83357013379057348645e-02 + w * s2;
+    s2 = -7.69187620504482999495e-02 + w * s2;
+    s2 = -1.11111104054623557880e-01 + w * s2;
+    s2 = -1.99999999998764832476e-01 + w * s2;
+    s2 = w * s2;
+    if (!reduced) return t - t * (s1 + s2);
+    double r = hi - ((t * (s1 + s2) - lo) - t);
+    return neg ? -r : r;
+}
+
+/* atan2(y, x) with C's special cases; the angle of the quotient, moved to the quadrant of (x, y). */
+RT_DM_HD double det_atan2(double y, double x) {
+    const double pi = 3.1415926535897931160e+00, pi_lo = 1.2246467991473531772e-16;
+    const double pio2 = 1.5707963267948965580e+00, pio4 = 7.8539816339744827900e-01;
+    if (x != x || y != y) return x + y;
+    uint64_t bx, by;
+    memcpy(&bx, &x, sizeof bx);
+    memcpy(&by, &y, sizeof by);
+    const int m = (int)(by >> 63) | ((int)(bx >> 63) << 1); /* bit 0: y negative, bit 1: x negative */
+    const uint64_t ax = bx & 0x7FFFFFFFFFFFFFFFull, ay = by & 0x7FFFFFFFFFFFFFFFull;
+    const uint64_t inf = 0x7FF0000000000000ull;
+    if (ay == 0) return m == 0 ? 0.0 : (m == 1 ? -0.0 : (m == 2 ? pi : -pi));
+    if (ax == 0) return (m & 1) ? -pio2 : pio2;
+    if (ax == inf) {
+        if (ay == inf) return m == 0 ? pio4 : (m == 1 ? -pio4 : (m == 2 ? 3.0 * pio4 : -3.0 * pio4));
+        return m == 0 ? 0.0 : (m == 1 ? -0.0 : (m == 2 ? pi : -pi));
+    }
+    if (ay == inf) return (m & 1) ? -pio2 : pio2;
+    const int k = (int)(ay >> 52) - (int)(ax >> 52);
+    double z;
+    int q = m;
+    if (k > 60) { z = pio2 + 0.5 * pi_lo; q = m & 1; }  /* |y / x| > 2^60 */
+    else if ((m & 2) && k < -60) z = 0.0;               /* |y / x| < 2^-60, x < 0 */
+    else {
+        double quo = y / x;
+        z = det_atan(quo < 0.0 ? -quo : quo);
+    }
+    if (q == 0) return z;
+    if (q == 1) return -z;
+    if (q == 2) return pi - (z - pi_lo);
+    return (z - pi_lo) - pi;
+}
+
+/* acos(x): rational approximation R(z) = P(z) / Q(z) of (asin(t) - t) / t^3 on z = t^2 <= 1/4; for |x| > 1/2 through
+ * acos x = 2 asin(sqrt((1 - x) / 2)), with the square root's rounding error carried for x > 1/2. */
+RT_DM_HD double det_acos_r(double z) {
+    double p = 3.47933107596021167570e-05;
+    p = 7.91534994289814532176e-04 + z * p;
+    p = -4.00555345006794114027e-02 + z * p;
+    p = 2.01212532134862925881e-01 + z * p;
+    p = -3.25565818622400915405e-01 + z * p;
+    p = 1.66666666666666657415e-01 + z * p;
+    p = z * p;
+    double q = 7.70381505559019352791e-02;
+    q = -6.88283971605453293030e-01 + z * q;
+    q = 2.02094576023350569471e+00 + z * q;
+    q = -2.40339491173441421878e+00 + z * q;
+    q = 1.0 + z * q;
+    return p / q;
+}
+RT_DM_HD double det_acos(double x) {
+    const double pi = 3.14159265358979311600e+00;
+    const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
+    if (x != x) return x + x;
+    const double a = x < 0.0 ? -x : x;
+    if (a >= 1.0) {
+        if (a == 1.0) return x > 0.0 ? 0.0 : pi + 2.0 * pio2_lo;
+        return (x - x) / (x - x); /* NaN */
+    }
+    if (a < 0.5) {
+        if (a <= 6.938893903907228e-18) return pio2_hi + pio2_lo; /* 2^-57 */
+        double r = det_acos_r(x * x);
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    if (x < 0.0) {
+        double z = (1.0 + x) * 0.5;
+        double s = __builtin_sqrt(z);
+        double w = det_acos_r(z) * s - pio2_lo;
+        return pi - 2.0 * (s + w);
+    }
+    double z = (1.0 - x) * 0.5;
+    double s = __builtin_sqrt(z);
+    uint64_t sb;
+    memcpy(&sb, &s, sizeof sb);
+    sb &= 0xFFFFFFFF00000000ull;
+    double df;
+    memcpy(&df, &sb, sizeof df);
+    double c = (z - df * df) / (s + df);
+    double w = det_acos_r(z) * s + c;
+    return 2.0 * (df + w);
 }
 
 #endif /* RT_DETMATH_H */

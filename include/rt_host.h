@@ -36,6 +36,11 @@ const RtCameraDesc* rth_camera(const RtHost* host);
 const RtRenderParams* rth_params(const RtHost* host);
 uint32_t rth_gpus(const RtHost* host);            /* --gpus, default 1 */
 uint32_t rth_samples_per_pixel(const RtHost* host); /* Camera::samples_per_pixel() */
+/* Row partition of `rtrace --gpus=N` (replaces the per-thread full-frame buffers of src/camera.rs:243-255): band height
+ * for `height` image rows over `n_parts` GPUs = the largest of 16, 8, 4, 2, 1 rows that gives the most loaded part as few
+ * rows as any of them does (the slowest GPU sets the time of the frame); 0 for n_parts <= 1.  The ONE definition of the
+ * rule on the native side; rust_raytracer_amd/dist.py (band_rows_for) is its Python twin and a test compares the two. */
+uint32_t rth_band_rows(uint32_t height, uint32_t n_parts);
 /* Everything the reference would have printed while loading ("Loaded N tris",
  * loader warnings), newline separated. */
 const char* rth_log(const RtHost* host);

@@ -567,8 +567,8 @@ struct Sphere : Hit {
         double u = 0.0, v = 0.0;
         Vec4 tangent = vec(1.0, 0.0, 0.0), bitangent = vec(1.0, 0.0, 0.0);
         if (!skip_uvs) {
-            double theta = std::acos(normal[1]);
-            double phi = std::atan2(-normal[2], normal[0]) + PI;
+            double theta = det_acos(normal[1]);  // f64::acos / atan2 (sphere.rs:69-70) through the shared deterministic functions
+            double phi = det_atan2(-normal[2], normal[0]) + PI;
             tangent = vec(-normal[2], 0.0, -normal[0]);
             bitangent = cross(normal, tangent);
             u = phi / (2.0 * PI);
@@ -944,7 +944,7 @@ struct Sky : Hit {
         Vec4 hit_pos = ray.at(hit_t);
         Vec4 unit_dir = to_unit(ray.dir);
         Vec4 normal = -unit_dir;
-        double u = std::atan2(unit_dir.x(), unit_dir.z()) / (2.0 * PI) + 0.5;
+        double u = det_atan2(unit_dir.x(), unit_dir.z()) / (2.0 * PI) + 0.5;
         double v = dot(unit_dir, vec(0.0, 1.0, 0.0)) / 2.0 + 0.5;
         out = make_hit(ray, hit_pos, hit_t, u, v, normal, vec(1, 0, 0), vec(1, 0, 0), material, material_index);
         return true;
@@ -1541,6 +1541,12 @@ int oracle_texture_sample(const RtSceneDesc* scene, uint32_t tex, double u, doub
 void oracle_detmath(double x, double* out3) {
     det_sincos(x, &out3[0], &out3[1]);
     out3[2] = x > 0 ? det_log(x) : 0.0;
+}
+
+void oracle_detmath_inv(double y, double x, double* out3) {
+    out3[0] = det_atan(y);
+    out3[1] = det_atan2(y, x);
+    out3[2] = det_acos(y);
 }
 
 double oracle_reflectance(double cos_theta, double ior_ratio) { return reflectance(cos_theta, ior_ratio); }

@@ -64,6 +64,8 @@ int oracle_lights_pdf_value(const RtSceneDesc* scene, const double origin[3], co
 int oracle_lights_random(const RtSceneDesc* scene, const double origin[3], uint64_t seed, uint32_t n, double* out3n);
 /* include/rt_detmath.h: out3 = det_sin(x), det_cos(x), det_log(x) */
 void oracle_detmath(double x, double* out3);
+/* out3 = det_atan(y), det_atan2(y, x), det_acos(y) */
+void oracle_detmath_inv(double y, double x, double* out3);
 /* utils.rs:31-36 */
 /* texture/*.rs Sampler::sample of texture `tex` at (u, v, p) */
 int oracle_texture_sample(const RtSceneDesc* scene, uint32_t tex, double u, double v, const double p[3], double* out3);

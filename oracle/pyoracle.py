@@ -54,6 +54,8 @@ def load() -> C.CDLL:
         lib.oracle_lights_random.restype = C.c_int
         lib.oracle_detmath.argtypes = [C.c_double, dp]
         lib.oracle_detmath.restype = None
+        lib.oracle_detmath_inv.argtypes = [C.c_double, C.c_double, dp]
+        lib.oracle_detmath_inv.restype = None
         lib.oracle_texture_sample.argtypes = [C.POINTER(api.RtSceneDesc), C.c_uint32, C.c_double, C.c_double, dp, dp]
         lib.oracle_texture_sample.restype = C.c_int
         lib.oracle_reflectance.argtypes = [C.c_double, C.c_double]
@@ -205,6 +207,13 @@ def onb_from_vec(w) -> np.ndarray:
 def refract(v, n, ior_ratio) -> np.ndarray:
     out = (C.c_double * 3)()
     load().oracle_refract(_d3(v), _d3(n), ior_ratio, out)
+    return np.array(list(out))
+
+
+def detmath_inv(y, x=1.0) -> np.ndarray:
+    """(det_atan(y), det_atan2(y, x), det_acos(y)) of include/rt_detmath.h."""
+    out = (C.c_double * 3)()
+    load().oracle_detmath_inv(float(y), float(x), out)
     return np.array(list(out))
 
 

@@ -152,6 +152,8 @@ def load_host_lib() -> C.CDLL:
         lib.rth_params.restype = C.POINTER(RtRenderParams)
         lib.rth_gpus.argtypes = [C.c_void_p]
         lib.rth_gpus.restype = C.c_uint32
+        lib.rth_band_rows.argtypes = [C.c_uint32, C.c_uint32]
+        lib.rth_band_rows.restype = C.c_uint32
         lib.rth_samples_per_pixel.argtypes = [C.c_void_p]
         lib.rth_samples_per_pixel.restype = C.c_uint32
         lib.rth_log.argtypes = [C.c_void_p]

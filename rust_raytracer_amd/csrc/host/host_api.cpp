@@ -76,6 +76,20 @@ const RtSceneDesc* rth_scene(const RtHost* host) { return host->desc; }
 const RtCameraDesc* rth_camera(const RtHost* host) { return &host->camera; }
 const RtRenderParams* rth_params(const RtHost* host) { return &host->params; }
 uint32_t rth_gpus(const RtHost* host) { return host->config.gpus; }
+uint32_t rth_band_rows(uint32_t height, uint32_t n_parts) {
+    if (n_parts <= 1) return 0;
+    uint32_t band = 16, best_rows = 0xFFFFFFFFu;
+    for (uint32_t b : {16u, 8u, 4u, 2u, 1u}) {
+        uint32_t most = 0;
+        for (uint32_t g = 0; g < n_parts; g++) {
+            uint32_t rows = 0;
+            for (uint32_t y = 0; y < height; y++) rows += ((y / b) % n_parts == g);
+            most = rows > most ? rows : most;
+        }
+        if (most < best_rows) { best_rows = most; band = b; }
+    }
+    return band;
+}
 uint32_t rth_samples_per_pixel(const RtHost* host) {
     return host->params.sqrt_spt * host->params.sqrt_spt * host->params.thread_count;  // camera.rs:50-51
 }

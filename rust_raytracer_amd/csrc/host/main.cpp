@@ -5,11 +5,12 @@
 //
 // New, optional flags (ignored by the reference's parser, so command lines stay compatible):
 //   --seed=<u64>  --gpus=<n>  --precision=f64|f32  --pipeline=auto|mega|wavefront  --bvh=host|device
-// With --gpus=n the frame is row-tiled in interleaved bands (16 rows, or finer when that balances the GPUs), one host thread per GPU;
-// the tiles are assembled on the host here (bench.py shows the RCCL gather path used for the
-// multi-process launch).
+// With --gpus=n the frame is row-tiled in interleaved bands (rth_band_rows: 16 rows, or finer when that balances the GPUs), one
+// host thread per GPU; the tiles are assembled on the host here (bench.py shows the RCCL gather path used for the
+// multi-process launch).  RT_RTRACE_ONE_DEVICE=1 (tests on a one-GPU box): every part renders on device 0.
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -51,22 +52,11 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "Error: no HIP device (the render path has no CPU fallback)\n");
         return 1;
     }
-    if (int(gpus) > available) gpus = uint32_t(available);
+    const char* one_dev = std::getenv("RT_RTRACE_ONE_DEVICE");
+    const bool rehearsal = one_dev && std::atoi(one_dev) != 0;
+    if (!rehearsal && int(gpus) > available) gpus = uint32_t(available);
     const uint32_t W = cam->image_width, H = cam->image_height;
-    // interleaved row bands: 16 rows unless a finer band gives the most loaded GPU fewer rows (it sets the time of the frame)
-    uint32_t band = 16;
-    if (gpus > 1) {
-        uint32_t best_rows = 0xFFFFFFFFu;
-        for (uint32_t b : {16u, 8u, 4u, 2u, 1u}) {
-            uint32_t most = 0;
-            for (uint32_t g = 0; g < gpus; g++) {
-                uint32_t rows = 0;
-                for (uint32_t y = 0; y < H; y++) rows += ((y / b) % gpus == g);
-                most = rows > most ? rows : most;
-            }
-            if (most < best_rows) { best_rows = most; band = b; }
-        }
-    }
+    const uint32_t band = gpus > 1 ? rth_band_rows(H, gpus) : 16;  // interleaved row bands
     std::vector<double> frame(size_t(W) * H * 4, 0.0);  // camera.create_buffer(), main.rs:74
     std::vector<std::string> errors(gpus);
     std::vector<std::thread> workers;
@@ -74,7 +64,7 @@ int main(int argc, char** argv) {
         workers.emplace_back([&, g]() {
             auto tg = clock::now();
             RtScene* scene = nullptr;
-            if (rt_scene_create(rth_scene(host), int(g), &scene) != RT_OK) {
+            if (rt_scene_create(rth_scene(host), rehearsal ? 0 : int(g), &scene) != RT_OK) {
                 errors[g] = rt_last_error();
                 return;
             }

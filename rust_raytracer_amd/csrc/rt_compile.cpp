@@ -433,14 +433,6 @@ struct Compiler {
                 Bounds<double> mbox;
                 if (!mesh_geometry_for(n.mesh, &mi.node_base, &mi.tri_base, &mi.max_depth, &mi.node4_base, &mbox)) return false;
                 out.mesh_bounds.push_back(mbox);
-                {   // S >= every |coordinate| of the mesh box, as f32 rounded up (error bounds of the f32 triangle pre-test)
-                    double S = 0.0;
-                    for (int a = 0; a < 3; a++) S = std::fmax(S, std::fmax(std::fabs(mbox.lo[a]), std::fabs(mbox.hi[a])));
-                    float Sf = std::isfinite(S) ? float(S) : 0.0f;
-                    if (double(Sf) < S) Sf = std::nextafterf(Sf, INFINITY);
-                    Sf = Sf * 1.0000002f + 1e-30f;
-                    std::memcpy(&mi.extent_bits, &Sf, sizeof Sf);
-                }
                 mi.material = n.material;
                 mi.flags = d.meshes[n.mesh].flags & (RT_MESH_FLAT_SHADING | RT_MESH_HIT_BACK_FACES);
                 if (d.meshes[n.mesh].tri_uv) mi.flags |= MESH_HAS_UV;

@@ -157,8 +157,12 @@ template <typename R> RT_DEV V3<R> random_cosine(Rng& g) {  // vec4.rs:50-61
 // materialises the thirteen f64 polynomial coefficients of acos (and atan2's) in VGPR pairs at the top of the kernel - they are
 // loop-invariant - and keeps them live through the whole of k_wf_shade, 26 registers of a kernel whose occupancy is set by its
 // registers, for code that only sphere and sky hits execute.  A call costs those hits a few dozen cycles.
-template <typename R> __attribute__((noinline)) RT_DEV R uv_acos(R x) { return acos(x); }
-template <typename R> __attribute__((noinline)) RT_DEV R uv_atan2(R y, R x) { return atan2(y, x); }
+// f64: the deterministic functions shared with the oracle (include/rt_detmath.h): u and v feed texel lookups and checker
+// parities, where a one-ulp difference between libms would flip a whole texel; f32 (no bit parity): the device libm.
+__attribute__((noinline)) RT_DEV double uv_acos(double x) { return det_acos(x); }
+__attribute__((noinline)) RT_DEV double uv_atan2(double y, double x) { return det_atan2(y, x); }
+__attribute__((noinline)) RT_DEV float uv_acos(float x) { return acosf(x); }
+__attribute__((noinline)) RT_DEV float uv_atan2(float y, float x) { return atan2f(y, x); }
 
 // ------------------------------------------------------------------ ray.rs
 template <typename R>
@@ -904,7 +908,7 @@ template <typename R, bool FULL> RT_DEV V3<R> lights_random(const SceneView<R>& 
 
 // ------------------------------------------------------------------ camera.rs:260-280, 334-349
 template <typename R>
-RT_DEV Ray<R> get_ray(const CameraView<R>& cam, uint32_t px, uint32_t py, uint32_t sx, uint32_t sy, Rng& rng) {
+RT_DEV void camera_ray(const CameraView<R>& cam, uint32_t px, uint32_t py, uint32_t sx, uint32_t sy, Rng& rng, V3<R>& origin_out, V3<R>& dir_out) {
     V3<R> pdu = ld3(cam.pdu), pdv = ld3(cam.pdv);
     V3<R> pixel_center = ld3(cam.first_pixel) + (pdu * R(px)) + (pdv * R(py));
     R rx = rng_uniform<R>(rng);
@@ -922,7 +926,14 @@ RT_DEV Ray<R> get_ray(const CameraView<R>& cam, uint32_t px, uint32_t py, uint32
         dy = dy / len;
         origin = origin + (ld3(cam.basis_u) * dx + ld3(cam.basis_v) * dy) * cam.aperture_radius;
     }
-    return make_ray(origin, pixel_sample - origin);
+    origin_out = origin;
+    dir_out = pixel_sample - origin;
+}
+template <typename R>
+RT_DEV Ray<R> get_ray(const CameraView<R>& cam, uint32_t px, uint32_t py, uint32_t sx, uint32_t sy, Rng& rng) {
+    V3<R> o, d;
+    camera_ray(cam, px, py, sx, sy, rng, o, d);
+    return make_ray(o, d);
 }
 
 // ------------------------------------------------------------------ one path vertex (camera.rs:282-332)

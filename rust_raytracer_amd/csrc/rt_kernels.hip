@@ -16,7 +16,6 @@
 #include "rt_compile.h"
 #include "rt_device.h"
 #include "rt_wavefront.h"
-#include "rt_mesh32.h"
 
 namespace rt {
 
@@ -389,18 +388,6 @@ struct DeviceScene {
             cast_arr(tris[i].v0, cs.tris[i].v0); cast_arr(tris[i].e1, cs.tris[i].e1); cast_arr(tris[i].e2, cs.tris[i].e2);
             tris[i]._pad = R(0);
         }
-        std::vector<TriRec32> tris32(cs.tris.size());
-        for (size_t i = 0; i < tris32.size(); i++) {
-            const auto& t = cs.tris[i];
-            TriRec32& r = tris32[i];
-            double L = 0.0;
-            for (int a = 0; a < 3; a++) {
-                r.v0[a] = float(t.v0[a]); r.e1[a] = float(t.e1[a]); r.e2[a] = float(t.e2[a]);
-                L = std::fmax(L, std::fmax(std::fabs(t.e1[a]), std::fabs(t.e2[a])));
-            }
-            r.L = round_up<float>(L) * 1.0000002f;  // >= max(|e1|_inf, |e2|_inf)
-            r._p0 = r._p1 = 0.f;
-        }
         std::vector<TriAttr<R>> attrs(cs.attrs.size());
         for (size_t i = 0; i < attrs.size(); i++) {
             const auto& s = cs.attrs[i];
@@ -446,7 +433,6 @@ struct DeviceScene {
         if ((st = buf.upload(nodes4q, &view.nodes4q)) != RT_OK) return st;
         if ((st = buf.upload(mesh_bounds, &view.mesh_bounds)) != RT_OK) return st;
         if ((st = buf.upload(tris, &view.tris)) != RT_OK) return st;
-        if ((st = buf.upload(tris32, &view.tris32)) != RT_OK) return st;
         if ((st = buf.upload(attrs, &view.attrs)) != RT_OK) return st;
         if ((st = buf.upload(cs.materials, &view.materials)) != RT_OK) return st;
         if ((st = buf.upload(mparams, &view.material_params)) != RT_OK) return st;
@@ -517,7 +503,7 @@ struct RtScene {
         void* pool_dev = nullptr;      // the same descriptor in device memory (k_wf_shade re-reads the array bases from it)
         uint32_t* queue[2] = {nullptr, nullptr};
         uint32_t* mesh_queue = nullptr;
-        uint32_t* fallback_queue = nullptr; // paths k_wf_mesh32 hands back to k_wf_mesh (candidate list full)
+        rt::SampleCtr* d_sctr = nullptr;   // sample counters of the current replica group (k_wf_shade restarts)
         void* mesh_spill = nullptr;        // k_wf_mesh: stack levels beyond the LDS part
         size_t mesh_spill_bytes = 0;
         rt::WfCounters* d_ctr = nullptr;
@@ -636,8 +622,6 @@ static void wf_release_pool(RtScene::Wavefront& w) {
     }
     if (w.mesh_queue) (void)hipFree(w.mesh_queue);
     w.mesh_queue = nullptr;
-    if (w.fallback_queue) (void)hipFree(w.fallback_queue);
-    w.fallback_queue = nullptr;
 }
 
 template <typename R>
@@ -663,15 +647,14 @@ int wf_ensure(RtScene* s, uint32_t capacity) {
         if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->depth))) return st;
         if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->hpc))) return st;
         if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->htri))) return st;
-        pool->cn = nullptr;   // candidate lists of the two-stage mesh search: allocated on first use (wf_ensure_candidates)
-        pool->ctri = nullptr;
-        pool->cand_stride = capacity;
+        if (int st = alloc((size_t(capacity) / 64 + 1) * 4, reinterpret_cast<void**>(&pool->qcur))) return st;
         for (int q = 0; q < 2; q++) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.queue[q]), size_t(capacity) * 4));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.mesh_queue), size_t(capacity) * 4));
         HIP_TRY(hipMalloc(&w.pool_dev, sizeof(WfPool<R>)));
         HIP_TRY(hipMemcpy(w.pool_dev, pool, sizeof(WfPool<R>), hipMemcpyHostToDevice));
         if (!w.d_ctr) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.d_ctr), sizeof(WfCounters)));
         if (!w.h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w.h_ctr), sizeof(WfCounters)));
+        if (!w.d_sctr) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.d_sctr), sizeof(SampleCtr) * kSampleCounters));
         if (w.events.empty()) {
             w.events.resize(136);  // 4 per iteration, up to 32 iterations between host checks, + 2 for the stand-alone prims launch
             for (auto& e : w.events) e = nullptr;
@@ -685,26 +668,6 @@ int wf_ensure(RtScene* s, uint32_t capacity) {
     }
     w.capacity = capacity;
     w.real_size = sizeof(R);
-    return RT_OK;
-}
-
-// Buffers of the two-stage mesh search (rt_mesh32.h), only when that variant is selected: 28 B per pool slot.
-template <typename R>
-int wf_ensure_candidates(RtScene* s) {
-    RtScene::Wavefront& w = s->wf;
-    auto* pool = static_cast<WfPool<R>*>(w.pool_view);
-    if (pool->cn) return RT_OK;
-    const size_t capacity = w.capacity;
-    void* p = nullptr;
-    HIP_TRY(hipMalloc(&p, capacity * 4));
-    w.allocs.push_back(p);
-    pool->cn = static_cast<uint32_t*>(p);
-    HIP_TRY(hipMalloc(&p, capacity * 4 * kMeshCandCap));
-    w.allocs.push_back(p);
-    pool->ctri = static_cast<uint32_t*>(p);
-    pool->cand_stride = capacity;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.fallback_queue), capacity * 4));
-    HIP_TRY(hipMemcpy(w.pool_dev, pool, sizeof(WfPool<R>), hipMemcpyHostToDevice));
     return RT_OK;
 }
 
@@ -736,8 +699,6 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     if (capacity < 64) capacity = 64;
     if (int st = wf_ensure<R>(s, capacity)) return st;
     RtScene::Wavefront& w = s->wf;
-    if (env_u32("RT_WF_MESH32", 0) != 0)
-        if (int st = wf_ensure_candidates<R>(s)) return st;
     WfPool<R> pool = *static_cast<WfPool<R>*>(w.pool_view);
 
     // per-sample radiance buffer: as many replicas per group as the memory budget allows
@@ -784,11 +745,8 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     if (n_mesh_ops != 1 || env_u32("RT_WF_SPLIT", 1) == 0 || vol) mesh_pc = -1;  // a volume's draws happen in program order
     const bool prims_only = n_mesh_ops == 0 && env_u32("RT_WF_SPLIT", 1) != 0 && !vol;
     const bool split = mesh_pc >= 0;
-    // the primitive program runs inside k_wf_shade on every new ray (k_wf_prims only for the camera rays of k_wf_generate)
-    // (not for the texture-interpreter variant: fused it needs more than 256 VGPRs, i.e. one wave per SIMD)
-    const bool fuse = (split || prims_only) && !s->compiled.needs_tex_interpreter && env_u32("RT_WF_FUSE", 0) != 0;  // measured slower than the separate pass (profiles/r02/ab/fuse_prims_into_shade.txt): off by default
     // k_wf_mesh keeps (child, entry distance) pairs: a shallow LDS part (occupancy) + a global spill part
-    // BVH node format of k_wf_mesh: 1 = 4-wide quantised (BvhNode4q, 64 B, default), 0 = 4-wide f32 (BvhNode4f, 128 B; A/B).
+    // BVH node format of k_wf_mesh: 1 = 4-wide quantised (BvhNode4q, 64 B, default), 0 = 4-wide f32 (BvhNode4f, 128 B; A/B control).
     // An 8-wide quantised node (a third fewer visits) was slower: profiles/r02/ab/node_width_and_size.txt.
     const int node_kind = env_u32("RT_WF_NODES", 1) != 0 ? 1 : 0;
     const int mesh_levels = int(s->compiled.max_bvh4_stack) + 1;
@@ -803,23 +761,8 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
         blocks_per_cu = std::min<int>(blocks_per_cu, int(env_u32("RT_WF_MESH_BLOCKS", 64)));  // experiments: occupancy scaling
     }
     const uint32_t isect_blocks = uint32_t(n_cu) * uint32_t(blocks_per_cu);
-    // two-stage mesh search (rt_mesh32.h): conservative f32 traversal + exact tests on the candidates; meshes that hit
-    // back faces keep the one-stage kernel
-    bool mesh32 = split && pool.cn != nullptr && env_u32("RT_WF_MESH32", 0) != 0;  // measured slower than the one-stage kernel (profiles/r02/ab/two_stage_mesh32.txt): off by default
-    if (mesh32 && (s->compiled.meshes[size_t(s->compiled.ops[size_t(mesh_pc)].arg)].flags & RT_MESH_HIT_BACK_FACES)) mesh32 = false;
-    const int lds_levels32 = std::min<int>(mesh_levels, int(env_u32("RT_WF_LDS_LEVELS32", 12)));
-    const size_t lds_mesh32 = size_t(lds_levels32) * 256 * sizeof(uint2) + 4 * kMesh32WaveLds;
-    uint32_t mesh32_blocks = isect_blocks;
-    if (mesh32) {
-        int b32 = 0;
-        if (stats) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b32, k_wf_mesh32<R, true>, 256, lds_mesh32));
-        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b32, k_wf_mesh32<R, false>, 256, lds_mesh32));
-        if (b32 < 1) b32 = 1;
-        b32 = std::min<int>(b32, int(env_u32("RT_WF_MESH32_BLOCKS", 64)));
-        mesh32_blocks = uint32_t(n_cu) * uint32_t(b32);
-    }
     if (split) {
-        size_t need = size_t(std::max(mesh_levels - std::min(lds_levels, lds_levels32), 1)) * std::max(isect_blocks, mesh32_blocks) * 256 * sizeof(uint2);
+        size_t need = size_t(std::max(mesh_levels - lds_levels, 1)) * isect_blocks * 256 * sizeof(uint2);
         if (need > w.mesh_spill_bytes) {
             if (w.mesh_spill) (void)hipFree(w.mesh_spill);
             w.mesh_spill = nullptr;
@@ -838,6 +781,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     const uint32_t check_every = trace_pool ? 1u : std::min<uint32_t>(32u, std::max<uint32_t>(1u, env_u32("RT_WF_CHECK", 8)));  // 4 timing events per iteration, 128 events
     const bool tex = s->compiled.needs_tex_interpreter;
     const size_t shade_lds_pad = env_u32("RT_WF_SHADE_LDS_PAD", 0);  // experiments: fewer resident blocks of the shade kernel
+    const uint32_t reserve_pct = std::min<uint32_t>(100u, env_u32("RT_WF_RESERVE_PCT", 6));  // share of the restarts served by the shared sample counters
 
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
@@ -851,66 +795,59 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
         WfGroup<R> grp{};
         grp.total = per_replica * nrep;
         grp.npix = npix;
+        grp.per_replica = per_replica;
+        grp.inv_per_replica = 1.0 / double(per_replica);
+        grp.inv_npix = 1.0 / double(npix);
+        grp.inv_width = 1.0 / double(cam.image_width);
         grp.tid0 = t0;
         grp.strata = strata;
+        if (grp.total >= (1ull << 51)) return set_err(RT_E_UNSUPPORTED, "more than 2^51 samples in one replica group");
         uint32_t first = uint32_t(std::min<uint64_t>(capacity, grp.total));
+        // private quotas of the groups of 64 slots: all but `reserve_pct` percent of the samples that k_wf_generate does not
+        // start; the rest goes through the shared counters (rt_wavefront.h, SampleCtr)
+        grp.quota_base = first;
+        grp.quota_groups = first / 64;
+        grp.quota = 0;
+        if (grp.quota_groups > 0 && reserve_pct < 100) {
+            const uint64_t q = uint64_t(double(grp.total - first) * (1.0 - 0.01 * double(reserve_pct)) / double(grp.quota_groups));
+            grp.quota = uint32_t(std::min<uint64_t>(q, 1ull << 31));
+        }
+        const uint64_t shared_from = grp.quota_base + uint64_t(grp.quota_groups) * grp.quota;
+        HIP_TRY(hipMemsetAsync(pool.qcur, 0, (size_t(first) / 64 + 1) * 4, stream));
         pool.capacity = first;  // slots in use by this group: the kernels address slots directly while all of them are queued
         WfCounters init{};
         init.n_in = first;
         init.n_out = 0;
         init.cursor = 0;
         init.n_mesh = 0;
-        init.n_mesh_next = 0;
-        init.n_fallback = 0;
-        init.cursor_fb = 0;
-        init.next_sample = first;
+        init.dry_mask = 0;
         *w.h_ctr = init;
         HIP_TRY(hipMemcpyAsync(w.d_ctr, w.h_ctr, sizeof(WfCounters), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_wf_init_samples, dim3(1), dim3(64), 0, stream, w.d_sctr, shared_from, uint64_t(grp.total), w.d_ctr);
         hipLaunchKernelGGL((k_wf_generate<R>), dim3((first + 255) / 256), dim3(256), 0, stream, pool, first, grp, cv, pv, w.queue[0]);
         int qi = 0;
         uint32_t upper = first;  // upper bound of the queue length (never grows: slots are reused in place)
 #define RT_LAUNCH_PRIMS(ST, L) hipLaunchKernelGGL((k_wf_prims<R, ST, L>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), lds_small + (WF_CHUNK + 4) * 4, stream, ds.view, pool, w.queue[qi], w.mesh_queue, w.d_ctr, s->d_counters, mesh_pc)
 #define RT_LAUNCH_PRIMS_ANY() do { if (stats) { if (lds_tables) RT_LAUNCH_PRIMS(true, true); else RT_LAUNCH_PRIMS(true, false); } \
                                    else { if (lds_tables) RT_LAUNCH_PRIMS(false, true); else RT_LAUNCH_PRIMS(false, false); } } while (0)
-        if (fuse) {  // camera rays of k_wf_generate: the only rays the fused shade kernel has not seen
-            HIP_TRY(hipEventRecord(w.events[0], stream));
-            RT_LAUNCH_PRIMS_ANY();
-            HIP_TRY(hipEventRecord(w.events[1], stream));
-        }
 #define RT_LAUNCH_MESH_V(ST, ND, QUEUE, NPTR, CPTR) hipLaunchKernelGGL((k_wf_mesh<R, ST, ND>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, QUEUE, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels, NPTR, CPTR)
 #define RT_LAUNCH_MESH(QUEUE, NPTR, CPTR)                                                                                                         \
     do {                                                                                                                                          \
         if (stats) { if (node_kind == 1) RT_LAUNCH_MESH_V(true, 1, QUEUE, NPTR, CPTR); else RT_LAUNCH_MESH_V(true, 0, QUEUE, NPTR, CPTR); } \
         else { if (node_kind == 1) RT_LAUNCH_MESH_V(false, 1, QUEUE, NPTR, CPTR); else RT_LAUNCH_MESH_V(false, 0, QUEUE, NPTR, CPTR); }       \
     } while (0)
-        bool first_round = true;
         for (;;) {
             size_t ev = 0;
-            if (fuse && first_round) ev = 2;  // events 0 / 1 bracket the stand-alone prims launch above
-            const size_t ev0 = ev;
-            // near the end of the last group the host looks after every second iteration, so that the tail is seen when it starts
-            const bool near_end = s->tail_flag && t0 + nrep >= T && w.h_ctr->next_sample + 4ull * pool.capacity >= grp.total;
+            // near the end of the last group (a sample counter has run dry: the others follow within a few percent of the
+            // render) the host looks after every second iteration, so that the tail is seen when it starts
+            const bool near_end = s->tail_flag && t0 + nrep >= T && w.h_ctr->dry_mask != 0ull;
             const uint32_t check_now = near_end ? std::min<uint32_t>(check_every, 2u) : check_every;
             for (uint32_t k = 0; k < check_now; k++) {
                 HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 if (split || prims_only) {
-                    if (!fuse) RT_LAUNCH_PRIMS_ANY();
+                    RT_LAUNCH_PRIMS_ANY();
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
-                    if (prims_only) { /* nothing deferred: the primitive program is the whole closest-hit search */ }
-                    else if (mesh32) {
-                        const dim3 chunks((upper + WF_CHUNK - 1) / WF_CHUNK);
-                        if (stats) {
-                            hipLaunchKernelGGL((k_wf_mesh32<R, true>), dim3(mesh32_blocks), dim3(256), lds_mesh32, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels32);
-                            hipLaunchKernelGGL((k_wf_mesh_exact<R, true>), chunks, dim3(256), 0, stream, ds.view, pool, w.mesh_queue, w.fallback_queue, w.d_ctr, s->d_counters, mesh_pc);
-                            RT_LAUNCH_MESH(w.fallback_queue, &w.d_ctr->n_fallback, &w.d_ctr->cursor_fb);
-                        } else {
-                            hipLaunchKernelGGL((k_wf_mesh32<R, false>), dim3(mesh32_blocks), dim3(256), lds_mesh32, stream, ds.view, pool, w.mesh_queue, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels32);
-                            hipLaunchKernelGGL((k_wf_mesh_exact<R, false>), chunks, dim3(256), 0, stream, ds.view, pool, w.mesh_queue, w.fallback_queue, w.d_ctr, s->d_counters, mesh_pc);
-                            RT_LAUNCH_MESH(w.fallback_queue, &w.d_ctr->n_fallback, &w.d_ctr->cursor_fb);
-                        }
-                    } else {
-                        RT_LAUNCH_MESH(w.mesh_queue, &w.d_ctr->n_mesh, &w.d_ctr->cursor);
-                    }
+                    if (!prims_only) RT_LAUNCH_MESH(w.mesh_queue, &w.d_ctr->n_mesh, &w.d_ctr->cursor);
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 } else {
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
@@ -920,13 +857,11 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
 #undef RT_LAUNCH_ISECT
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 }
-#define RT_LAUNCH_SHADE(ST, L, TX, FU) hipLaunchKernelGGL((k_wf_shade<R, ST, L, TX, FU>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), (L ? lds_small : size_t(0)) + ((FU ? 3 : 2) * WF_CHUNK + 8) * 4 + shade_lds_pad, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters, w.mesh_queue, mesh_pc, static_cast<const WfPool<R>*>(w.pool_dev))
-#define RT_LAUNCH_SHADE_F(ST, L, TX) do { if (fuse) RT_LAUNCH_SHADE(ST, L, TX, true); else RT_LAUNCH_SHADE(ST, L, TX, false); } while (0)
+#define RT_LAUNCH_SHADE(ST, L, TX) hipLaunchKernelGGL((k_wf_shade<R, ST, L, TX>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), (L ? lds_small : size_t(0)) + (WF_CHUNK + 4) * 4 + shade_lds_pad, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.d_sctr, w.sample_L, s->d_counters, static_cast<const WfPool<R>*>(w.pool_dev))
                 if (tex) {  // interpreter variant: tables from global memory (rare scenes, fewer instantiations)
-                    if (stats) RT_LAUNCH_SHADE_F(true, false, true); else RT_LAUNCH_SHADE_F(false, false, true);
-                } else if (stats) { if (lds_tables) RT_LAUNCH_SHADE_F(true, true, false); else RT_LAUNCH_SHADE_F(true, false, false); }
-                else { if (lds_tables) RT_LAUNCH_SHADE_F(false, true, false); else RT_LAUNCH_SHADE_F(false, false, false); }
-#undef RT_LAUNCH_SHADE_F
+                    if (stats) RT_LAUNCH_SHADE(true, false, true); else RT_LAUNCH_SHADE(false, false, true);
+                } else if (stats) { if (lds_tables) RT_LAUNCH_SHADE(true, true, false); else RT_LAUNCH_SHADE(true, false, false); }
+                else { if (lds_tables) RT_LAUNCH_SHADE(false, true, false); else RT_LAUNCH_SHADE(false, false, false); }
 #undef RT_LAUNCH_SHADE
                 hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(1), 0, stream, w.d_ctr);
                 HIP_TRY(hipEventRecord(w.events[ev++], stream));
@@ -936,13 +871,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(w.h_ctr, w.d_ctr, sizeof(WfCounters), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
-            if (fuse && first_round) {
-                float ms = 0.f;
-                HIP_TRY(hipEventElapsedTime(&ms, w.events[0], w.events[1]));
-                phase_ms[0] += ms;
-            }
-            first_round = false;
-            for (size_t e = ev0; e + 3 < ev; e += 4) {
+            for (size_t e = 0; e + 3 < ev; e += 4) {
                 float it_ms[3];
                 for (int ph = 0; ph < 3; ph++) {
                     it_ms[ph] = 0.f;
@@ -1018,7 +947,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     st.node_visits = hc.node_visits;
     st.tri_tests = hc.tri_tests;
     st.prim_tests = hc.prim_tests;
-    st.bytes_node = split ? (mesh32 || node_kind == 0 ? sizeof(BvhNode4f) : sizeof(BvhNode4q)) : sizeof(BvhNode<R>);
+    st.bytes_node = split ? (node_kind == 0 ? sizeof(BvhNode4f) : sizeof(BvhNode4q)) : sizeof(BvhNode<R>);
     st.bytes_tri = sizeof(TriRec<R>);
     st.bytes_attr = sizeof(TriAttr<R>);
     // path state moved by the DOMINANT kernel per ray it traverses: ray (6 R) + bound/op read (R + 4)
@@ -1028,7 +957,6 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     // sample index in, ray + throughput + rng + depth out (a path that ends writes 24 B of radiance instead and restarts)
     st.bytes_state_prims = 6 * sizeof(R) + 3 * sizeof(R) + 8;
     st.bytes_state_shade = (6 + 3 + 3) * sizeof(R) + 8 + 8 + 4 + 8 + (6 + 3) * sizeof(R) + 8 + 4;
-    if (fuse) st.bytes_state_shade += 3 * sizeof(R) + 8 + 4;  // + closest primitive hit of the new ray and its mesh-queue entry
     if (!split) st.mesh_rays = hc.rays;  // combined kernel: every ray's state passes through it
     return RT_OK;
 }
@@ -1104,6 +1032,7 @@ void rt_scene_destroy(RtScene* s) {
     rt::wf_release_pool(s->wf);
     if (s->wf.mesh_spill) (void)hipFree(s->wf.mesh_spill);
     if (s->wf.d_ctr) (void)hipFree(s->wf.d_ctr);
+    if (s->wf.d_sctr) (void)hipFree(s->wf.d_sctr);
     if (s->wf.h_ctr) (void)hipHostFree(s->wf.h_ctr);
     if (s->wf.sample_L) (void)hipFree(s->wf.sample_L);
     if (s->wf.acc) (void)hipFree(s->wf.acc);

@@ -87,7 +87,7 @@ struct MeshInst {
     uint32_t n_tris;
     uint32_t max_depth;
     uint32_t node4_base;  // first BvhNode4f of this mesh in nodes4[]
-    uint32_t extent_bits; // f32 bits of S >= every |coordinate| of the mesh's box (error bounds of k_wf_mesh32)
+    uint32_t _pad;
 };
 constexpr uint32_t MESH_HAS_UV = 0x100u;
 
@@ -134,13 +134,6 @@ template <typename R>
 struct alignas(16) TriRec {
     R v0[3], e1[3], e2[3];
     R _pad;
-};
-// f32 copy of a triangle record for the conservative pre-test of k_wf_mesh32 (rt_mesh32.h): values rounded to nearest,
-// L >= max(|e1|_inf, |e2|_inf) rounded up.  48 B, three 16-B loads.
-struct alignas(16) TriRec32 {
-    float v0[3], L;
-    float e1[3], _p0;
-    float e2[3], _p1;
 };
 // Shading attributes, fetched only for the final closest hit.
 template <typename R>
@@ -215,11 +208,10 @@ struct SceneView {
     const MeshInst* meshes;
     const VolumeRec<R>* volumes;   // global memory (not in the LDS blob)
     const BvhNode<R>* nodes;
-    const BvhNode4f* nodes4;       // 4-wide f32 nodes (k_wf_mesh32, k_wf_mesh with RT_WF_NODES=0)
+    const BvhNode4f* nodes4;       // 4-wide f32 nodes (k_wf_mesh with RT_WF_NODES=0: A/B control)
     const BvhNode4q* nodes4q;      // the same nodes, quantised to 64 B (k_wf_mesh)
     const Bounds<R>* mesh_bounds;  // per mesh instance: exact box of its triangles (object space)
     const TriRec<R>* tris;
-    const TriRec32* tris32;        // same slots, f32 (k_wf_mesh32)
     const TriAttr<R>* attrs;
     const MaterialRec* materials;
     const MaterialParams<R>* material_params;
@@ -263,8 +255,6 @@ struct DeviceCounters {
     // k_wf_mesh lane utilisation (collect_stats): wave-level iterations of the node / triangle / refill code and
     // the lanes that were active in them (utilisation = lanes / (64 * waves)); printed with RT_WF_DEBUG=1
     unsigned long long node_wave_iters, tri_wave_iters, refill_wave_iters, refill_lanes, pops_culled;
-    // two-stage mesh search (rt_mesh32.h): candidates the f32 stage kept, exact tests run on them, paths handed to k_wf_mesh
-    unsigned long long candidates, exact_tests, cand_overflows;
 };
 
 }  // namespace rt

@@ -40,11 +40,7 @@ struct WfPool {
     uint32_t* depth;                 // remaining depth (the `depth` argument of ray_color)
     R *ht, *hu, *hv;                 // closest hit: t, (u, v)
     int32_t *hpc, *htri;             // op that produced it (-1 none), triangle slot
-    // two-stage mesh search (rt_mesh32.h): per path the number of candidate triangles (kMeshCandOverflow: list full) and
-    // the candidates themselves, candidate k of slot s at ctri[k * cand_stride + s]
-    uint32_t* cn;
-    uint32_t* ctri;
-    size_t cand_stride;
+    uint32_t* qcur;                  // per 64 consecutive slots: samples taken from that group's private quota (WfGroup::quota)
 };
 
 // Element `slot` of a pool array through a 32-bit BYTE offset.  `base + zext(offset)` lets the compiler address every
@@ -67,48 +63,76 @@ struct WfCounters {
     uint32_t n_in;        // entries of the current queue
     uint32_t n_out;       // entries appended to the next queue
     uint32_t cursor;      // next queue entry to hand out (persistent intersect / mesh kernel)
-    uint32_t n_mesh;      // entries of the mesh queue (paths whose ray enters the deferred mesh's box)
-    uint32_t n_mesh_next; // mesh queue being filled by the fused shade kernel for the NEXT iteration (k_wf_advance moves it to n_mesh)
-    uint32_t n_fallback;  // paths whose candidate list overflowed in k_wf_mesh32: re-done by k_wf_mesh
-    uint32_t cursor_fb;   // ... and the cursor of that run
-    uint32_t _pad;
-    unsigned long long next_sample;  // next sample (within the group) to start
+    uint32_t n_mesh;      // entries of the mesh queue (paths whose ray enters a deferred mesh's box)
+    unsigned long long dry_mask;  // bit k: sample counter k has handed out its whole range (all ones: no sample left to start)
+};
+
+// Samples that have not been started yet are handed out in two tiers, so that k_wf_shade can restart a finished path IN
+// PLACE, in the trip that shaded it, without waiting for anything:
+//  1. a PRIVATE QUOTA per 64 consecutive pool slots (WfGroup::quota, ~94 % of the samples): while the whole pool is alive
+//     those 64 slots are always handled by one wave in one trip, which reads the group's cursor (WfPool::qcur) with the
+//     path state and writes it back: no atomic, no extra round trip.  (A returning atomic add per wave and trip - the first
+//     form of this kernel - cost 37 % of its time: the wave's only memory round trip per trip became two.)
+//  2. K shared counters for the rest, each over its own contiguous range of sample indices and on its own 128-byte line:
+//     one returning atomic add per wave that needs samples its quota no longer has.  One word sustains ~83 such atomics
+//     per microsecond, 64 words ~3200 (tools/ubench/atomic_rate.hip, profiles/r03/ubench_atomic_rate.txt).  A wave starts
+//     at counter (wave index mod K) and moves on for good when a counter runs dry; the wave whose add crosses the end of a
+//     range records it in WfCounters::dry_mask.  Groups consume their quotas at the same rate within a few percent, so the
+//     shared tier is what the fast groups live on until the slow ones are done.
+// In the tail of a render (pool no longer full: slots are compacted, a wave's lanes belong to different groups) a lane
+// takes what is left of its group's quota with a per-lane atomic.  Which sample a slot gets does not matter for the frame:
+// every sample owns its slot of the per-sample radiance buffer.
+constexpr uint32_t kSampleCounters = 64;
+struct alignas(128) SampleCtr {
+    unsigned long long next;  // next sample index to hand out (runs past `hi` once dry)
+    unsigned long long hi;    // end of this counter's range
+    unsigned long long _pad[14];
 };
 
 // Sample s of a replica group -> (replica, stratum, owned pixel).  Pixels run fastest so that a
-// wave starts 64 neighbouring pixels of one stratum: coherent primary rays, coalesced buffers.
+// wave starts neighbouring pixels of one stratum: coherent primary rays, coalesced buffers.
 template <typename R>
 struct WfGroup {
-    uint64_t total;      // samples in this group = n_replicas * S*S * npix
-    uint64_t npix;       // owned pixels
-    uint32_t tid0;       // first replica of the group
-    uint32_t strata;     // S*S
+    uint64_t total;        // samples in this group = n_replicas * S*S * npix  (< 2^51, checked by the driver)
+    uint64_t npix;         // owned pixels
+    uint64_t per_replica;  // S*S * npix
+    double inv_per_replica, inv_npix, inv_width;  // reciprocals rounded to nearest: quotient ESTIMATES, made exact in div_by
+    uint32_t tid0;         // first replica of the group
+    uint32_t strata;       // S*S
+    // Unrendered samples are handed out in two tiers (see SampleCtr): every 64 consecutive pool slots own a private
+    // quota of `quota` samples starting at quota_base + (slot / 64) * quota, the rest is shared through the counters.
+    uint64_t quota_base;   // first sample index of the quotas = samples started by k_wf_generate
+    uint32_t quota;        // samples per group of 64 slots (0: none)
+    uint32_t quota_groups; // groups that have a quota (the complete ones: capacity / 64)
 };
 
+// floor(a / b) and the remainder for a < 2^51: the reciprocal estimate is off by at most one, the remainder test makes it
+// exact (integers throughout: nothing here can move a pixel).  A generic 64-bit division is ~120 instructions on gfx950
+// and the restart of a finished path needs three of them.
+RT_DEV uint64_t div_by(uint64_t a, uint64_t b, double inv_b, uint64_t& rem) {
+    uint64_t q = uint64_t(double(a) * inv_b);
+    int64_t r = int64_t(a - q * b);
+    if (r < 0) { q--; r += int64_t(b); }
+    else if (r >= int64_t(b)) { q++; r -= int64_t(b); }
+    rem = uint64_t(r);
+    return q;
+}
+
+// Camera ray (origin, direction) and RNG state of sample s, in registers (camera.rs:260-280 through camera_ray).
 template <typename R>
-RT_DEV Ray<R> wf_start_sample(const WfPool<R>& pool, uint32_t slot, uint64_t s, const WfGroup<R>& grp,
-                              const CameraView<R>& cam, const ParamsView<R>& prm) {
-    uint64_t per_replica = uint64_t(grp.strata) * grp.npix;
-    uint32_t tid_local = uint32_t(s / per_replica);
-    uint64_t rem = s - uint64_t(tid_local) * per_replica;
-    uint32_t st = uint32_t(rem / grp.npix);
-    uint64_t pix = rem - uint64_t(st) * grp.npix;
-    uint32_t row = uint32_t(pix / cam.width), px = uint32_t(pix - uint64_t(row) * cam.width);
+RT_DEV void wf_new_sample(uint64_t s, const WfGroup<R>& grp, const CameraView<R>& cam, const ParamsView<R>& prm, V3<R>& o, V3<R>& d, Rng& rng) {
+    uint64_t rem, pix, px64;
+    const uint32_t tid_local = uint32_t(div_by(s, grp.per_replica, grp.inv_per_replica, rem));
+    const uint32_t st = uint32_t(div_by(rem, grp.npix, grp.inv_npix, pix));
+    const uint32_t row = uint32_t(div_by(pix, cam.width, grp.inv_width, px64));
+    const uint32_t px = uint32_t(px64);
     uint32_t py;
     if (prm.band_rows == 0 || prm.n_parts <= 1) py = row;
     else py = ((row / prm.band_rows) * prm.n_parts + prm.part) * prm.band_rows + (row % prm.band_rows);
-    uint32_t S = cam.sqrt_spt;
-    uint32_t sy = st / S, sx = st - sy * S;
-    Rng rng;
+    const uint32_t S = cam.sqrt_spt;
+    const uint32_t sy = st / S, sx = st - sy * S;
     rng.key(prm.seed, grp.tid0 + tid_local, uint64_t(py) * cam.width + px, st);
-    Ray<R> ray = get_ray(cam, px, py, sx, sy, rng);
-    at(pool.ox, slot) = ray.o.x; at(pool.oy, slot) = ray.o.y; at(pool.oz, slot) = ray.o.z;
-    at(pool.dx, slot) = ray.d.x; at(pool.dy, slot) = ray.d.y; at(pool.dz, slot) = ray.d.z;
-    at(pool.tr, slot) = R(1); at(pool.tg, slot) = R(1); at(pool.tb, slot) = R(1);
-    at(pool.rng, slot) = rng.s;
-    at(pool.sample, slot) = s;
-    at(pool.depth, slot) = cam.max_depth;
-    return ray;
+    camera_ray(cam, px, py, sx, sy, rng, o, d);
 }
 
 template <typename R>
@@ -116,8 +140,29 @@ __global__ void __launch_bounds__(256) k_wf_generate(WfPool<R> pool, uint32_t co
                                                      ParamsView<R> prm, uint32_t* __restrict__ queue) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    wf_start_sample(pool, i, uint64_t(i), grp, cam, prm);
+    V3<R> o, d;
+    Rng rng;
+    wf_new_sample(uint64_t(i), grp, cam, prm, o, d, rng);
+    at(pool.ox, i) = o.x; at(pool.oy, i) = o.y; at(pool.oz, i) = o.z;
+    at(pool.dx, i) = d.x; at(pool.dy, i) = d.y; at(pool.dz, i) = d.z;
+    at(pool.tr, i) = R(1); at(pool.tg, i) = R(1); at(pool.tb, i) = R(1);
+    at(pool.rng, i) = rng.s;
+    at(pool.sample, i) = uint64_t(i);
+    at(pool.depth, i) = cam.max_depth;
     queue[i] = i;
+}
+
+// The K sample counters of a replica group: samples [0, first) are started by k_wf_generate, counter k owns an equal share
+// of [first, total).
+__global__ void k_wf_init_samples(SampleCtr* sctr, uint64_t first, uint64_t total, WfCounters* ctr) {
+    const uint32_t k = threadIdx.x;
+    if (k >= kSampleCounters) return;
+    const uint64_t rest = total - first;
+    const uint64_t lo = first + rest * k / kSampleCounters, hi = first + rest * (k + 1) / kSampleCounters;
+    sctr[k].next = lo;
+    sctr[k].hi = hi;
+    unsigned long long dry = __ballot(lo >= hi);
+    if (k == 0) ctr->dry_mask = dry;
 }
 
 // Number of lanes below `lane` whose bit is set in `mask` (v_mbcnt_lo/hi).
@@ -524,8 +569,6 @@ RT_DEV bool prims_search(const SceneView<R>& sc, const Ray<R>& wray, int32_t mes
     return to_mesh;
 }
 
-// Stand-alone form: only the FIRST iteration of a replica group needs it (the camera rays of k_wf_generate); from
-// then on k_wf_shade<FUSE> runs prims_search on every new ray while it is still in registers.
 #ifndef RT_PRIMS_WAVES
 #define RT_PRIMS_WAVES 5  // 95 VGPRs without scratch since the mesh-box test moved to the mesh op (round 2); 4 waves before: 171 -> 157 ms per step
 #endif
@@ -903,33 +946,63 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Shade: one path vertex per lane (camera.rs:295-331), regeneration and queue compaction.
+// Shade: one path vertex per lane (camera.rs:295-331), regeneration in place and queue compaction.
 // ---------------------------------------------------------------------------------------------
 // Waves per SIMD asked of the register allocator for k_wf_shade: 4 (<= 128 VGPRs) for the lean variant.  It needs 106 since
 // the inverse trigonometric functions of the UV maps are called out of line (uv_acos / uv_atan2 in rt_device.h: inlined, their
 // polynomial coefficients sat in 50 VGPRs for the whole kernel); 166 and 3 waves before that, 188-197 and 2 waves in round 1.
-// 5 waves (96 VGPRs + 16 B of scratch) are slower.  The fused variant needs 125-130 registers, the texture-interpreter
-// variants 174-189: no cap for them.
+// 5 waves (96 VGPRs + 16 B of scratch) are slower.  The texture-interpreter variants need 174-189: no cap for them.
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4
 #endif
-#define RT_SHADE_BOUNDS __launch_bounds__(256, (TEX || FUSE) ? 1 : RT_SHADE_WAVES)
-// FUSE: the scene has the split intersect (one mesh op, or none): the primitive program (prims_search) runs HERE on
-// every new ray — scattered or regenerated — while it is still in registers, writes the closest primitive hit and
-// queues the ray for k_wf_mesh.  Without it a separate k_wf_prims pass re-read every ray from the pool each iteration
-// (48 B in, 40 B out per ray, one more launch per iteration: 12 % of the headline step in round 1).
-template <typename R, bool STATS, bool LDS, bool TEX, bool FUSE>
+#define RT_SHADE_BOUNDS __launch_bounds__(256, TEX ? 1 : RT_SHADE_WAVES)
+
+// Sample indices for the lanes in `m` (the wave's finished paths), in lane order: ONE returning atomic add per wave on the
+// wave's current counter; a counter that cannot serve the whole request serves what it has left and the wave moves on to
+// the next one for good.  Returns ~0 in lanes that get none (every counter is dry: the render is in its tail).
+// k: the wave's current counter (wave-uniform, kept across calls); dry: WfCounters::dry_mask as this wave knows it.
+RT_DEV unsigned long long wave_reserve_samples(SampleCtr* __restrict__ sctr, WfCounters* __restrict__ ctr, uint32_t& k, unsigned long long& dry,
+                                               unsigned long long m) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n = uint32_t(__popcll(m));
+    const uint32_t rank = lane_prefix(m);
+    const int leader = __ffsll((long long)m) - 1;
+    const bool mine = ((m >> lane) & 1ull) != 0ull;
+    unsigned long long s = ~0ull;
+    uint32_t got = 0;
+    while (got < n && dry != ~0ull) {
+        if ((dry >> k) & 1ull) {  // known to be dry: next counter
+            k = (k + 1u) % kSampleCounters;
+            continue;
+        }
+        const uint32_t want = n - got;
+        unsigned long long old = 0;
+        if (int(lane) == leader) old = atomicAdd(&sctr[k].next, (unsigned long long)want);
+        old = __shfl(old, leader);
+        const unsigned long long hi = sctr[k].hi;
+        const uint32_t avail = old < hi ? uint32_t(min((unsigned long long)want, hi - old)) : 0u;
+        if (mine && rank >= got && rank < got + avail) s = old + (rank - got);
+        got += avail;
+        if (old + want >= hi) {  // this request reached the end of the range
+            dry |= 1ull << k;
+            // exactly one request CROSSES the end: that wave publishes it (one atomic per counter and render, not per wave)
+            if (old < hi && int(lane) == leader) atomicOr(&ctr->dry_mask, 1ull << k);
+            k = (k + 1u) % kSampleCounters;
+        }
+    }
+    return s;
+}
+
+template <typename R, bool STATS, bool LDS, bool TEX>
 __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam, ParamsView<R> prm, WfPool<R> pool, WfGroup<R> grp,
                                            const uint32_t* __restrict__ queue_in, uint32_t* __restrict__ queue_out,
-                                           WfCounters* __restrict__ ctr, double* __restrict__ sample_L, DeviceCounters* counters,
-                                           uint32_t* __restrict__ mesh_queue, int32_t mesh_pc, const WfPool<R>* __restrict__ pool_dev) {
+                                           WfCounters* __restrict__ ctr, SampleCtr* __restrict__ sctr, double* __restrict__ sample_L,
+                                           DeviceCounters* counters, const WfPool<R>* __restrict__ pool_dev) {
     extern __shared__ __align__(16) char lds_raw[];
     uint32_t* alive_list = reinterpret_cast<uint32_t*>(lds_raw);  // [WF_CHUNK] slots that go to the next queue
-    uint32_t* dead_list = alive_list + WF_CHUNK;                 // [WF_CHUNK] slots whose path ended
-    uint32_t* mesh_list = dead_list + WF_CHUNK;                  // [WF_CHUNK] (FUSE) slots whose new ray must visit the mesh
-    uint32_t* lc = mesh_list + (FUSE ? WF_CHUNK : 0u);           // [0] n_alive [1] n_dead [2,3] sample base [4] queue base [5] n_mesh [6] mesh queue base
-    char* tables = reinterpret_cast<char*>(lc + 8);
-    if (threadIdx.x < 8) lc[threadIdx.x] = 0;
+    uint32_t* lc = alive_list + WF_CHUNK;                        // [0] n_alive [1] queue base
+    char* tables = reinterpret_cast<char*>(lc + 4);
+    if (threadIdx.x < 4) lc[threadIdx.x] = 0;
     SceneView<R> sc = sc_g;
     if constexpr (LDS) sc = scene_tables_to_lds(sc_g, tables);
     else __syncthreads();
@@ -941,16 +1014,33 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
     const uint32_t begin = blockIdx.x * WF_CHUNK;
     const uint32_t end = min(n, begin + WF_CHUNK);
     LaneCounters cnt;
-    // ---- phase 1: one path vertex per lane, chunk by chunk ----
+    // sample counters: the wave's home counter and what is known to be dry (a relaxed device-scope load: other waves publish
+    // crossings while this kernel runs; a stale value costs one more atomic, never a sample)
+    uint32_t sk = (blockIdx.x * 4u + (threadIdx.x >> 6)) % kSampleCounters;
+    unsigned long long dry = __hip_atomic_load(&ctr->dry_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // One path vertex per lane, chunk by chunk.  A lane whose path ends stores the sample's radiance and starts the next
+    // unrendered sample IN PLACE, in the same trip: every lane then writes ONE complete state - its continuation or its new
+    // camera ray - so the 64 slots of a wave fill whole 128-byte lines of every pool array with one store instruction each.
+    // (Round 2 restarted the finished slots of a workgroup together in a second phase: the lines of a trip were written in two
+    // parts, 70 % of the lanes and later the other 30 %, and left the L2 in between: 1.8 x the bytes on the write side,
+    // profiles/r02/c4_f64 vs profiles/r03/c4_f64.)
     for (uint32_t base = begin; base < end; base += blockDim.x) {
         const uint32_t i = base + threadIdx.x;
         const bool active = i < end;
         bool alive = false;
-        bool to_mesh = false;
         uint32_t slot = 0;
+        PathState<R> ps;
+        ps.ray = make_ray(mk<R>(0, 0, 0), mk<R>(0, 0, 0));
+        ps.throughput = mk<R>(0, 0, 0);
+        ps.radiance = mk<R>(0, 0, 0);
+        ps.depth = 0;
+        Rng rng;
+        rng.s = 0;
+        // the quota cursor of the wave's 64 slots travels with the path state: loaded here, used after the shading
+        uint32_t qc = 0;
+        if (full && ((base + (threadIdx.x & ~63u)) >> 6) < grp.quota_groups) qc = at(pool.qcur, (base + (threadIdx.x & ~63u)) >> 6);
         if (active) {
             slot = full ? i : queue_in[i];
-            PathState<R> ps;
             ps.ray = make_ray(mk<R>(at(pool.ox, slot), at(pool.oy, slot), at(pool.oz, slot)), mk<R>(at(pool.dx, slot), at(pool.dy, slot), at(pool.dz, slot)));
             Best<R> best;
             best.t = at(pool.ht, slot); best.u = at(pool.hu, slot); best.v = at(pool.hv, slot);
@@ -961,9 +1051,7 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
             if (best.pc >= 0) hit = resolve_hit<R, TEX>(sc, ps.ray, best);
             asm volatile("" ::: "memory");
             ps.throughput = mk<R>(at(pool.tr, slot), at(pool.tg, slot), at(pool.tb, slot));
-            ps.radiance = mk<R>(0, 0, 0);
             ps.depth = at(pool.depth, slot);
-            Rng rng;
             rng.s = at(pool.rng, slot);
             bool cont;
             if (best.pc < 0) {  // camera.rs:331 background
@@ -974,23 +1062,7 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
             }
             ps.depth--;
             if (cont && ps.depth != 0) {  // depth == 0: ray_color returns black without tracing (camera.rs:290)
-                // The array bases are re-read HERE from a copy of the pool descriptor in global memory (scalar loads): with
-                // the kernel-argument copy the compiler kept the eleven load addresses alive as VGPR pairs across the
-                // whole shading code to reuse them for these stores (22 VGPRs of a kernel that is occupancy-bound).
-                asm volatile("" ::: "memory");
-                const WfPool<R>& pw = *pool_dev;
-                put_global(pw.ox, slot, ps.ray.o.x); put_global(pw.oy, slot, ps.ray.o.y); put_global(pw.oz, slot, ps.ray.o.z);
-                put_global(pw.dx, slot, ps.ray.d.x); put_global(pw.dy, slot, ps.ray.d.y); put_global(pw.dz, slot, ps.ray.d.z);
-                put_global(pw.tr, slot, ps.throughput.x); put_global(pw.tg, slot, ps.throughput.y); put_global(pw.tb, slot, ps.throughput.z);
-                put_global(pw.rng, slot, rng.s);
-                put_global(pw.depth, slot, ps.depth);
                 alive = true;
-                if constexpr (FUSE) {
-                    Best<R> nb;
-                    to_mesh = prims_search<R, STATS>(sc, ps.ray, mesh_pc, nb, cnt);
-                    at(pool.ht, slot) = nb.t; at(pool.hu, slot) = nb.u; at(pool.hv, slot) = nb.v;
-                    at(pool.hpc, slot) = nb.pc; at(pool.htri, slot) = nb.tri;
-                }
             } else {
                 if (cont) end_black(ps);  // depth exhausted: the next ray_color call returns black (camera.rs:290)
                 uint64_t s = at(pool.sample, slot);
@@ -999,57 +1071,64 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
                 sample_L[3 * s + 2] = double(ps.radiance.z);
             }
         }
-        lds_append(active && alive, slot, alive_list, &lc[0]);
-        lds_append(active && !alive, slot, dead_list, &lc[1]);
-        if constexpr (FUSE) lds_append(to_mesh, slot, mesh_list, &lc[5]);
-    }
-    __syncthreads();
-    // ---- phase 2: finished paths restart IN PLACE on the next samples (one global atomic per workgroup;
-    //      all lanes generate camera rays together: no divergence against the shading code) ----
-    const uint32_t n_dead = lc[1];
-    if (threadIdx.x == 0 && n_dead) {
-        unsigned long long b0 = atomicAdd(&ctr->next_sample, (unsigned long long)n_dead);
-        lc[2] = uint32_t(b0);
-        lc[3] = uint32_t(b0 >> 32);
-    }
-    __syncthreads();
-    const unsigned long long s_base = (unsigned long long)lc[2] | ((unsigned long long)lc[3] << 32);
-    for (uint32_t j0 = 0; j0 < n_dead; j0 += blockDim.x) {
-        const uint32_t j = j0 + threadIdx.x;
-        bool restarted = false;
-        bool to_mesh = false;
-        uint32_t slot = 0;
-        if (j < n_dead) {
-            const unsigned long long s2 = s_base + j;
-            slot = dead_list[j];
-            if (s2 < grp.total) {
-                const Ray<R> ray = wf_start_sample(pool, slot, s2, grp, cam, prm);
-                restarted = true;
-                if constexpr (FUSE) {
-                    Best<R> nb;
-                    to_mesh = prims_search<R, STATS>(sc, ray, mesh_pc, nb, cnt);
-                    at(pool.ht, slot) = nb.t; at(pool.hu, slot) = nb.u; at(pool.hv, slot) = nb.v;
-                    at(pool.hpc, slot) = nb.pc; at(pool.htri, slot) = nb.tri;
+        // The array bases are re-read HERE from a copy of the pool descriptor in global memory (scalar loads): with
+        // the kernel-argument copy the compiler kept the eleven load addresses alive as VGPR pairs across the
+        // whole shading code to reuse them for these stores (22 VGPRs of a kernel that is occupancy-bound).
+        asm volatile("" ::: "memory");
+        const WfPool<R>& pw = *pool_dev;
+        const bool is_dead = active && !alive;
+        unsigned long long dead = __ballot(is_dead);
+        if (dead != 0ull) {
+            unsigned long long s2 = ~0ull;
+            // tier 1: the private quota of this group of 64 slots
+            if (full) {
+                const uint32_t g = (base + (threadIdx.x & ~63u)) >> 6;  // wave-uniform: the wave's 64 slots are one group
+                if (g < grp.quota_groups && qc < grp.quota) {
+                    const uint32_t take = min(uint32_t(__popcll(dead)), grp.quota - qc);
+                    const uint32_t rank = lane_prefix(dead);
+                    if (is_dead && rank < take) s2 = grp.quota_base + uint64_t(g) * grp.quota + qc + rank;
+                    if ((threadIdx.x & 63u) == 0) pool.qcur[g] = qc + take;
+                }
+            } else if (is_dead) {
+                const uint32_t g = slot >> 6;
+                if (g < grp.quota_groups && at(pool.qcur, g) < grp.quota) {  // the cursor only grows: a stale value costs one atomic
+                    const uint32_t c = atomicAdd(&pool.qcur[g], 1u);
+                    if (c < grp.quota) s2 = grp.quota_base + uint64_t(g) * grp.quota + c;
                 }
             }
+            // tier 2: the shared counters
+            dead = __ballot(is_dead && s2 == ~0ull);
+            if (dead != 0ull && dry != ~0ull) {
+                const unsigned long long s3 = wave_reserve_samples(sctr, ctr, sk, dry, dead);
+                if (s2 == ~0ull) s2 = s3;
+            }
+            if (is_dead && s2 != ~0ull) {
+                V3<R> o, d;
+                wf_new_sample(s2, grp, cam, prm, o, d, rng);
+                ps.ray.o = o;
+                ps.ray.d = d;
+                ps.throughput = mk<R>(1, 1, 1);
+                ps.depth = cam.max_depth;
+                put_global(pw.sample, slot, (uint64_t)s2);
+                alive = true;
+            }
         }
-        lds_append(restarted, slot, alive_list, &lc[0]);
-        if constexpr (FUSE) lds_append(to_mesh, slot, mesh_list, &lc[5]);
+        if (alive) {
+            put_global(pw.ox, slot, ps.ray.o.x); put_global(pw.oy, slot, ps.ray.o.y); put_global(pw.oz, slot, ps.ray.o.z);
+            put_global(pw.dx, slot, ps.ray.d.x); put_global(pw.dy, slot, ps.ray.d.y); put_global(pw.dz, slot, ps.ray.d.z);
+            put_global(pw.tr, slot, ps.throughput.x); put_global(pw.tg, slot, ps.throughput.y); put_global(pw.tb, slot, ps.throughput.z);
+            put_global(pw.rng, slot, rng.s);
+            put_global(pw.depth, slot, ps.depth);
+        }
+        lds_append(alive, slot, alive_list, &lc[0]);
     }
     __syncthreads();
-    // ---- phase 3: surviving slots -> next queue, mesh list -> next mesh queue (one global atomic per workgroup and
-    //      list, coalesced copies) ----
+    // ---- surviving slots -> next queue (one global atomic per workgroup, coalesced copy) ----
     const uint32_t n_alive = lc[0];
-    const uint32_t n_list = FUSE ? lc[5] : 0u;
-    if (threadIdx.x == 0 && n_alive) lc[4] = atomicAdd(&ctr->n_out, n_alive);
-    if (FUSE && threadIdx.x == 64 && n_list) lc[6] = atomicAdd(&ctr->n_mesh_next, n_list);
+    if (threadIdx.x == 0 && n_alive) lc[1] = atomicAdd(&ctr->n_out, n_alive);
     __syncthreads();
-    const uint32_t qb = lc[4];
+    const uint32_t qb = lc[1];
     for (uint32_t j = threadIdx.x; j < n_alive; j += blockDim.x) queue_out[qb + j] = alive_list[j];
-    if constexpr (FUSE) {
-        const uint32_t mb = lc[6];
-        for (uint32_t j = threadIdx.x; j < n_list; j += blockDim.x) mesh_queue[mb + j] = mesh_list[j];
-    }
     if (STATS) {
         uint32_t rays = cnt.rays, prims = cnt.prim_tests;
         for (int off = 32; off > 0; off >>= 1) { rays += __shfl_down(rays, off); prims += __shfl_down(prims, off); }
@@ -1065,10 +1144,7 @@ __global__ void k_wf_advance(WfCounters* ctr) {
     ctr->n_in = ctr->n_out;
     ctr->n_out = 0;
     ctr->cursor = 0;
-    ctr->n_mesh = ctr->n_mesh_next;  // filled by k_wf_shade<FUSE> (0 otherwise)
-    ctr->n_mesh_next = 0;
-    ctr->n_fallback = 0;
-    ctr->cursor_fb = 0;
+    ctr->n_mesh = 0;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -43,11 +43,15 @@ def band_rows_for(height: int, world_size: int) -> int:
     return best
 
 
-def partition_params(params: api.RtRenderParams, world_size: int, rank: int, height: int = 0) -> api.RtRenderParams:
-    """`height` = image rows (the band height is chosen for it; 0: 16-row bands)."""
+def partition_params(params: api.RtRenderParams, world_size: int, rank: int, height: int) -> api.RtRenderParams:
+    """`height` = image rows: the band height is chosen for it (band_rows_for), and `rows_of_part` / `max_rows` /
+    `gather_frame` derive the SAME band height from the same `height`, so a renderer and the de-interleave can never
+    disagree about which rows a rank owns."""
+    if height <= 0:
+        raise ValueError("partition_params needs the image height (the band height is chosen for it)")
     p = params.copy()
     if world_size > 1:
-        p.band_rows = band_rows_for(height, world_size) if height else BAND_ROWS
+        p.band_rows = band_rows_for(height, world_size)
         p.n_parts = world_size
         p.part = rank
     else:
@@ -57,11 +61,16 @@ def partition_params(params: api.RtRenderParams, world_size: int, rank: int, hei
     return p
 
 
-def rows_of_part(height: int, world_size: int, part: int, band_rows: int = 0) -> list:
+def rows_of_part(height: int, world_size: int, part: int) -> list:
+    """Image rows of `part`, in the order the renderer packs them (the band height is the one partition_params sets)."""
     if world_size <= 1:
         return list(range(height))
-    b = band_rows or band_rows_for(height, world_size)
-    return [y for y in range(height) if (y // b) % world_size == part]
+    return rows_of_part_banded(height, world_size, part, band_rows_for(height, world_size))
+
+
+def rows_of_part_banded(height: int, world_size: int, part: int, band_rows: int) -> list:
+    """The rows a given band height would give `part` (band_rows_for compares candidates; tests)."""
+    return [y for y in range(height) if (y // band_rows) % world_size == part]
 
 
 def max_rows(height: int, world_size: int) -> int:

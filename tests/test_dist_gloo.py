@@ -38,9 +38,12 @@ def test_partition_is_a_partition():
         for n in (2, 3, 4, 8):
             b = rtdist.band_rows_for(h, n)
             most = max(len(rtdist.rows_of_part(h, n, r)) for r in range(n))
-            assert all(most <= max(len(rtdist.rows_of_part(h, n, r, bb)) for r in range(n)) for bb in (16, 8, 4, 2, 1)), (h, n, b)
+            assert all(most <= max(len(rtdist.rows_of_part_banded(h, n, r, bb)) for r in range(n)) for bb in (16, 8, 4, 2, 1)), (h, n, b)
             p = rtdist.partition_params(api.RtRenderParams(), n, 0, h)
             assert p.band_rows == b and sorted(y for r in range(n) for y in rtdist.rows_of_part(h, n, r)) == list(range(h))
+            # `rtrace --gpus=N` (csrc/host/main.cpp) takes its band height from the native twin of the rule: the same choice
+            assert api.load_host_lib().rth_band_rows(h, n) == b, (h, n)
+    assert api.load_host_lib().rth_band_rows(1200, 1) == 0 and rtdist.band_rows_for(1200, 1) == 0
 
 
 @pytest.mark.parametrize("world", [2, 3])

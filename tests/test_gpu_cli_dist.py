@@ -27,8 +27,8 @@ def free_port():
     return p
 
 
-def run_rtrace(args, cwd):
-    r = subprocess.run([RTRACE] + args, cwd=cwd, capture_output=True, text=True, timeout=600)
+def run_rtrace(args, cwd, env=None):
+    r = subprocess.run([RTRACE] + args, cwd=cwd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     return r.stdout
 
@@ -64,6 +64,14 @@ def test_rtrace_binary_end_to_end(tmp_path):
     out_c = run_rtrace([os.path.join(REPO, "scenes", "light_test"), "-w=60", "-s=18", "-t=2", "--seed=2"], str(tmp_path / "c"))
     assert out_c.splitlines()[0] == "Loaded 15744 tris"                                          # loaders/obj.rs
     assert "Rendering: 60x40 @18spp on 2 threads (9 samples/thread)" in out_c
+    # --gpus=3 (rehearsed on this box's one GPU: RT_RTRACE_ONE_DEVICE=1 puts every part on device 0): three host threads, three
+    # row parts in rth_band_rows bands, assembled on the host: the same out.png, byte for byte, as --gpus=1
+    for sub, extra in (("d1", ["--gpus=1"]), ("d3", ["--gpus=3"])):
+        (tmp_path / sub).mkdir()
+        out_d = run_rtrace([os.path.join(REPO, "scenes", "light_test"), "-w=90", "-s=18", "-t=2", "--seed=2"] + extra, str(tmp_path / sub),
+                           env=dict(os.environ, RT_RTRACE_ONE_DEVICE="1"))
+        assert sum(1 for ln in out_d.splitlines() if re.fullmatch(rf"GPU \d finished in {dur}", ln)) == (3 if sub == "d3" else 1)
+    assert (tmp_path / "d3" / "out.png").read_bytes() == (tmp_path / "d1" / "out.png").read_bytes()
     # bad input: message on stderr, non-zero exit, no abort
     r = subprocess.run([RTRACE, "/nonexistent/scene"], cwd=str(tmp_path), capture_output=True, text=True)
     assert r.returncode == 1 and r.stderr.startswith("Error:")

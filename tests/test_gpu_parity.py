@@ -240,16 +240,16 @@ def test_every_kernel_variant_is_bit_identical(dev, name, monkeypatch):
     p.pipeline = api.RT_PIPELINE_WAVEFRONT
     for stats in (0, 1):
         for lds in ("1", "0"):
-            for split, fuse, mesh32, nodeq in (("1", "0", "0", "1"), ("1", "0", "0", "0"), ("1", "1", "0", "1"), ("1", "0", "1", "1"), ("0", "0", "0", "1")):
+            # (the round-2 variants that lost their A/B - primitive program fused into k_wf_shade, two-stage f32 mesh search -
+            # are no longer part of the library: commit 231b3c2 has them, profiles/r02/ab/ their records)
+            for split, nodeq in (("1", "1"), ("1", "0"), ("0", "1")):
                 monkeypatch.setenv("RT_LDS_TABLES", lds)
-                monkeypatch.setenv("RT_WF_NODES", nodeq)  # BVH nodes of k_wf_mesh: 1 = 64-B quantised (default), 0 = 128-B f32
-                monkeypatch.setenv("RT_WF_SPLIT", split)
-                monkeypatch.setenv("RT_WF_FUSE", fuse)    # primitive program inside k_wf_shade instead of a separate pass
-                monkeypatch.setenv("RT_WF_MESH32", mesh32)  # two-stage mesh search: conservative f32 traversal + exact tests on the candidates
+                monkeypatch.setenv("RT_WF_NODES", nodeq)  # BVH nodes of k_wf_mesh: 1 = 64-B quantised (default), 0 = 128-B f32 (A/B control)
+                monkeypatch.setenv("RT_WF_SPLIT", split)  # 0: combined intersect kernel for every scene
                 p.collect_stats = stats
                 wf = scene.render(hs.camera, p)
                 same = (wf == mega) | (np.isnan(wf) & np.isnan(mega))
-                assert same.all(), f"variant stats={stats} lds={lds} split={split} fuse={fuse} mesh32={mesh32} nodeq={nodeq}: {int((~same).any(axis=2).sum())} pixels differ"
+                assert same.all(), f"variant stats={stats} lds={lds} split={split} nodeq={nodeq}: {int((~same).any(axis=2).sum())} pixels differ"
 
 
 def _bumpy_grid_obj(path, n, offset, scale, flat=False):

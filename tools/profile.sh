@@ -7,6 +7,7 @@ source "$(dirname "$0")/gpu_steps.sh"
 tag=$1; shift
 R=$PWD; OUT=$R/gpurun_out/$tag; rm -rf "$OUT"; mkdir -p "$OUT"
 ARGS="--steps 1 --warmup 1 --no-cpu-baseline $*"
+cat rust_raytracer_amd/librt_mi355.so.srchash > "$OUT/lib_digest.txt"
 timeout -k 10 600 python bench.py --steps 3 --warmup 1 $* > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
 cd /tmp && export TMPDIR=/tmp
 prof() { local name=$1; shift; timeout -k 10 400 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- python3 "$R/bench.py" $ARGS > "$OUT/$name.log" 2>&1; local rc=$?; echo "$name rc=$rc"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit 1; fi; }
