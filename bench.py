@@ -42,6 +42,13 @@ WORKLOADS = {
     # sun + sky) at the size of samples/sample0.png; BASELINE config C1 is this scene at 400x266 @64spp on the CPU
     "c1": (["-w=1200", "-s=256", "-t=4"], "default scene (golden_monkey.rs) 1200x800 @256spp, 440 spheres in an object BVH + Suzanne 15.7k tri"),
     # rows f-3 / f-4 of SURVEY section 8: more than one mesh instance in `world`, and constant-density volumes
+    # the headline scene with a finer tessellation of the same stand-in surface: BVH nodes + triangle records (the traversal
+    # kernel's hot set) are 314 MB / 1.25 GB instead of 78 MB, i.e. beyond the 256 MB Infinity Cache (MI355X_MICROARCH.md:
+    # "scale past L3 before reading FETCH_SIZE"); scene file and OBJ are generated under build/bigmesh/ on first use
+    "c4_3m": (["build/bigmesh/cornell_dragon_3m", "-w=1200", "-s=1000", "-t=10"],
+              "scenes/cornell_dragon 1200x1200 @1000spp with the stand-in mesh at 1320x1320 quads = 3484800 triangles"),
+    "c4_14m": (["build/bigmesh/cornell_dragon_14m", "-w=1200", "-s=1000", "-t=10"],
+               "scenes/cornell_dragon 1200x1200 @1000spp with the stand-in mesh at 2640x2640 quads = 13939200 triangles"),
     "two_meshes": (["tests/scenes/two_meshes", "-w=800", "-s=256"], "tests/scenes/two_meshes 800x800 @256spp, two transformed mesh instances (2 x 967 tri)"),
     "smoke": (["scenes/cornell_smoke", "-w=800", "-s=256"], "scenes/cornell_smoke 800x800 @256spp, two constant-density volumes bounded by boxes"),
 }
@@ -56,6 +63,29 @@ def ensure_dragon():
         tmp = path + f".tmp{os.getpid()}"
         subprocess.run([tool, tmp], check=True)
         os.replace(tmp, path)
+
+
+BIG_MESHES = {"c4_3m": ("3m", 1320), "c4_14m": ("14m", 2640)}
+
+
+def ensure_big_dragon(workload: str):
+    """build/bigmesh/cornell_dragon_<tag> + dragon_<tag>.obj: scenes/cornell_dragon with tools/gen_dragon's surface at NU = NV = n."""
+    tag, n = BIG_MESHES[workload]
+    d = os.path.join(REPO, "build", "bigmesh")
+    os.makedirs(d, exist_ok=True)
+    obj = os.path.join(d, f"dragon_{tag}.obj")
+    if not os.path.exists(obj):
+        tool = os.path.join(REPO, "tools", "gen_dragon")
+        if not os.path.exists(tool):
+            subprocess.run(["g++", "-std=c++17", "-O2", "-o", tool, tool + ".cpp"], check=True)
+        tmp = obj + f".tmp{os.getpid()}"
+        subprocess.run([tool, tmp, str(n), str(n)], check=True)
+        os.replace(tmp, obj)
+    scene = os.path.join(d, f"cornell_dragon_{tag}")
+    text = open(os.path.join(REPO, "scenes", "cornell_dragon")).read().replace("resource/dragon_high.obj", f"dragon_{tag}.obj")
+    with open(scene + ".tmp", "w") as f:
+        f.write(text)
+    os.replace(scene + ".tmp", scene)
 
 
 def cpu_model() -> str:
@@ -391,9 +421,9 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    if a.workload == "c4":
+    if a.workload == "c4" or a.workload in BIG_MESHES:
         if rank == 0:
-            ensure_dragon()
+            ensure_dragon() if a.workload == "c4" else ensure_big_dragon(a.workload)
         if world > 1:
             dist.barrier()
     args, desc = WORKLOADS[a.workload]

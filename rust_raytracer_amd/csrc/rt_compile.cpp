@@ -350,7 +350,20 @@ struct Compiler {
                          m.n_triangles, opt.bvh_on_device ? "device LBVH" : "host binned-SAH", std::chrono::duration<double, std::milli>(t1 - t0).count(), bvh.nodes.size(), bvh.max_depth,
                          std::chrono::duration<double, std::milli>(t2 - t1).count(), bvh4.nodes.size());
         *node4_base = uint32_t(out.nodes4.size());
-        out.nodes4.insert(out.nodes4.end(), bvh4.nodes.begin(), bvh4.nodes.end());
+        // The 4-wide nodes carry ABSOLUTE references (node index into nodes4, first triangle slot into tris / attrs): k_wf_mesh
+        // serves every mesh instance of a scene, lane by lane, without per-mesh base registers.
+        if (out.tris.size() + m.n_triangles >= (1ull << 28)) return fail(RT_E_UNSUPPORTED, "more than 2^28 triangles in one scene");
+        for (BuildNode4 nd : bvh4.nodes) {
+            for (int k = 0; k < 4; k++) {
+                if (nd.child[k] == kEmptyChild) continue;
+                if (nd.child[k] >= 0) nd.child[k] += int32_t(*node4_base);
+                else {
+                    const uint32_t code = uint32_t(~nd.child[k]);
+                    nd.child[k] = ~int32_t((((code >> 3) + uint32_t(out.tris.size())) << 3) | (code & 7u));
+                }
+            }
+            out.nodes4.push_back(nd);
+        }
         if (bvh4.max_stack > out.max_bvh4_stack) out.max_bvh4_stack = bvh4.max_stack;
         for (int a = 0; a < 3; a++) { box->lo[a] = bvh4.root_lo[a]; box->hi[a] = bvh4.root_hi[a]; }
         mesh_node4_base[mi] = *node4_base;
@@ -853,6 +866,8 @@ int compile_scene(const RtSceneDesc* desc, CompiledScene* out, std::string* err,
     if (!c.compile_node(desc->world_root, 0)) return c.status;
     c.chain.clear();
     out->ops.push_back({OP_END, 0, 0, c.chain_id()});
+    for (size_t pc = 0; pc < out->ops.size(); pc++)
+        if (out->ops[pc].type == OP_MESH) out->mesh_ops.push_back(int32_t(pc));
     if (!c.compile_lights()) return c.status;
     c.decide_zero_weight_stop();
     out->chain_offsets.push_back(0);

@@ -21,7 +21,8 @@ struct CompiledScene {
     std::vector<MeshInst> meshes;
     std::vector<VolumeRec<double>> volumes;  // OP_VOL_* (world_test<VOL> / k_wf_intersect<VOL>)
     std::vector<BuildNode> nodes;            // all meshes, node indices relative to MeshInst::node_base
-    std::vector<BuildNode4> nodes4;          // 4-wide collapse, relative to MeshInst::node4_base
+    std::vector<BuildNode4> nodes4;          // 4-wide collapse, ABSOLUTE child / triangle references; a mesh's root is node MeshInst::node4_base
+    std::vector<int32_t> mesh_ops;           // pcs of the OP_MESH ops outside volumes, in program order (k_wf_prims defers them, k_wf_mesh serves them)
     std::vector<Bounds<double>> mesh_bounds; // per MeshInst
     uint32_t max_bvh4_stack = 1;
     std::vector<TriRec<double>> tris;        // leaf order

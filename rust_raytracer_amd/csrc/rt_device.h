@@ -346,6 +346,31 @@ template <typename R> RT_DEV Ray<R> ray_in_chain(const SceneView<R>& sc, const R
     return make_ray(o, d);
 }
 
+// Scene tables are never written by a kernel.  Reading them through a CONSTANT-address-space pointer tells the compiler so:
+// a load whose address is wave-uniform then becomes a scalar load (s_load into SGPRs, scalar cache) even behind the kernel's
+// own stores to other buffers, where it otherwise has to assume a clobber and issues a vector load.
+template <typename T> RT_DEV const __attribute__((address_space(4))) T* as_const_mem(const T* p) {
+    return (const __attribute__((address_space(4))) T*)(p);
+}
+// ray_in_chain for a WAVE-UNIFORM chain index (k_wf_mesh enters one mesh op at a time): chain and matrices through scalar loads.
+template <typename R> RT_DEV Ray<R> ray_in_chain_uniform(const SceneView<R>& sc, const Ray<R>& wray, int32_t chain) {
+    const auto* offs = as_const_mem(sc.chain_offsets);
+    const auto* items = as_const_mem(sc.chain_items);
+    const auto* xf = as_const_mem(sc.xforms);
+    int32_t b = offs[chain], e = offs[chain + 1];
+    if (b == e) return wray;
+    V3<R> o = wray.o, d = wray.d;
+    for (int32_t i = b; i < e; i++) {
+        R inv[12];
+        const int32_t x = items[i];
+#pragma unroll
+        for (int k = 0; k < 12; k++) inv[k] = xf[x].inv[k];
+        o = xform_apply(inv, o, R(1));
+        d = xform_apply(inv, d, R(0));
+    }
+    return make_ray(o, d);
+}
+
 // world.test(ray, Interval(t_lo, inf)) — closest hit over the whole scene program.
 // Reproduces ObjectList::test (list.rs:58-74), BoundingVolumeHierarchyNode::test
 // (bvh.rs:84-101) and Transform::test (transform.rs:122-139): depth-first, fixed order,
@@ -480,29 +505,34 @@ RT_DEV void world_test(const SceneView<R>& sc, const Ray<R>& wray, const R t_lo_
 }
 
 // ------------------------------------------------------------------ small tables in LDS
-// Copies the packed small tables into LDS (whole workgroup, 16 B per lane per trip) and returns a
-// view whose table pointers point into LDS.  Must be called by every thread of the block.
-template <typename R>
-RT_DEV SceneView<R> scene_tables_to_lds(const SceneView<R>& g, char* lds) {
-    const uint32_t n16 = (g.lay.total_bytes + 15u) / 16u;
-    const uint4* src = reinterpret_cast<const uint4*>(g.small_blob);
+// Copies the first `staged` bytes of a packed small-table blob into LDS (whole workgroup, 16 B per lane per trip) and
+// returns a view whose pointers to the tables that lie completely inside that prefix point into LDS; the others keep
+// pointing to global memory.  Must be called by every thread of the block.
+// ALL: the whole blob is staged (staged == lay.total_bytes): every table pointer is an LDS pointer and the compiler KNOWS it
+// (ds_read instructions).  Otherwise the choice is made at run time and the tables are read with flat instructions.
+template <typename R, bool ALL>
+RT_DEV SceneView<R> scene_tables_to_lds(const SceneView<R>& g, const SmallLayout& lay, const char* blob, char* lds, uint32_t staged) {
+    const uint32_t n16 = (staged + 15u) / 16u;
+    const uint4* src = reinterpret_cast<const uint4*>(blob);
     uint4* dst = reinterpret_cast<uint4*>(lds);
     for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
     SceneView<R> v = g;
-    v.ops = reinterpret_cast<const Op*>(lds + g.lay.ops);
-    v.bounds = reinterpret_cast<const Bounds<R>*>(lds + g.lay.bounds);
-    v.chain_offsets = reinterpret_cast<const int32_t*>(lds + g.lay.chain_offsets);
-    v.chain_items = reinterpret_cast<const int32_t*>(lds + g.lay.chain_items);
-    v.xforms = reinterpret_cast<const Xform<R>*>(lds + g.lay.xforms);
-    v.spheres = reinterpret_cast<const SpherePrim<R>*>(lds + g.lay.spheres);
-    v.planes = reinterpret_cast<const PlanePrim<R>*>(lds + g.lay.planes);
-    v.suns = reinterpret_cast<const SunPrim<R>*>(lds + g.lay.suns);
-    v.meshes = reinterpret_cast<const MeshInst*>(lds + g.lay.meshes);
-    v.materials = reinterpret_cast<const MaterialRec*>(lds + g.lay.materials);
-    v.material_params = reinterpret_cast<const MaterialParams<R>*>(lds + g.lay.material_params);
-    v.textures = reinterpret_cast<const TextureRec<R>*>(lds + g.lay.textures);
-    v.lights = reinterpret_cast<const LightRec*>(lds + g.lay.lights);
+#define RT_REMAP(field, T, tbl) if (ALL || lay.end[tbl] <= staged) v.field = reinterpret_cast<const T*>(lds + lay.begin[tbl])
+    RT_REMAP(ops, Op, ST_OPS);
+    RT_REMAP(bounds, Bounds<R>, ST_BOUNDS);
+    RT_REMAP(chain_offsets, int32_t, ST_CHAIN_OFFSETS);
+    RT_REMAP(chain_items, int32_t, ST_CHAIN_ITEMS);
+    RT_REMAP(xforms, Xform<R>, ST_XFORMS);
+    RT_REMAP(spheres, SpherePrim<R>, ST_SPHERES);
+    RT_REMAP(planes, PlanePrim<R>, ST_PLANES);
+    RT_REMAP(suns, SunPrim<R>, ST_SUNS);
+    RT_REMAP(meshes, MeshInst, ST_MESHES);
+    RT_REMAP(materials, MaterialRec, ST_MATERIALS);
+    RT_REMAP(material_params, MaterialParams<R>, ST_MATERIAL_PARAMS);
+    RT_REMAP(textures, TextureRec<R>, ST_TEXTURES);
+    RT_REMAP(lights, LightRec, ST_LIGHTS);
+#undef RT_REMAP
     return v;
 }
 

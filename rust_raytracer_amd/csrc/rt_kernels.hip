@@ -432,6 +432,20 @@ struct DeviceScene {
         if ((st = buf.upload(nodes4, &view.nodes4)) != RT_OK) return st;
         if ((st = buf.upload(nodes4q, &view.nodes4q)) != RT_OK) return st;
         if ((st = buf.upload(mesh_bounds, &view.mesh_bounds)) != RT_OK) return st;
+        if ((st = buf.upload(cs.mesh_ops, &view.mesh_ops)) != RT_OK) return st;
+        view.n_mesh_ops = int32_t(cs.mesh_ops.size());
+        std::vector<MeshOpRec<R>> mesh_op_recs(cs.mesh_ops.size());
+        for (size_t m = 0; m < mesh_op_recs.size(); m++) {
+            const Op& op = cs.ops[size_t(cs.mesh_ops[m])];
+            const MeshInst& mi = cs.meshes[size_t(op.arg)];
+            MeshOpRec<R>& r = mesh_op_recs[m];
+            r.pc = cs.mesh_ops[m];
+            r.chain = op.chain;
+            r.node4_base = mi.node4_base;
+            r.flags = mi.flags;
+            for (int a = 0; a < 3; a++) { r.lo[a] = mesh_bounds[size_t(op.arg)].lo[a]; r.hi[a] = mesh_bounds[size_t(op.arg)].hi[a]; }
+        }
+        if ((st = buf.upload(mesh_op_recs, &view.mesh_op_recs)) != RT_OK) return st;
         if ((st = buf.upload(tris, &view.tris)) != RT_OK) return st;
         if ((st = buf.upload(attrs, &view.attrs)) != RT_OK) return st;
         if ((st = buf.upload(cs.materials, &view.materials)) != RT_OK) return st;
@@ -441,32 +455,36 @@ struct DeviceScene {
         if ((st = buf.upload(perlin_vec, &view.perlin_vec)) != RT_OK) return st;
         if ((st = buf.upload(cs.perlin_perm, &view.perlin_perm)) != RT_OK) return st;
         if ((st = buf.upload(cs.lights, &view.lights)) != RT_OK) return st;
-        // the same small tables once more, packed for LDS staging
+        // the same small tables once more, packed for LDS staging: once in k_wf_prims' order, once in k_wf_shade's
         {
-            std::vector<char> blob;
-            auto put = [&](const void* data, size_t bytes) -> uint32_t {
-                size_t off = (blob.size() + 15) & ~size_t(15);
-                blob.resize(off + bytes);
-                if (bytes) std::memcpy(blob.data() + off, data, bytes);
-                return uint32_t(off);
+            struct Tbl { const void* data; size_t bytes; };
+            const Tbl tbl[ST_COUNT] = {
+                {cs.ops.data(), cs.ops.size() * sizeof(Op)}, {bounds.data(), bounds.size() * sizeof(Bounds<R>)},
+                {cs.chain_offsets.data(), cs.chain_offsets.size() * 4}, {cs.chain_items.data(), cs.chain_items.size() * 4},
+                {xforms.data(), xforms.size() * sizeof(Xform<R>)}, {spheres.data(), spheres.size() * sizeof(SpherePrim<R>)},
+                {planes.data(), planes.size() * sizeof(PlanePrim<R>)}, {suns.data(), suns.size() * sizeof(SunPrim<R>)},
+                {cs.meshes.data(), cs.meshes.size() * sizeof(MeshInst)}, {cs.materials.data(), cs.materials.size() * sizeof(MaterialRec)},
+                {mparams.data(), mparams.size() * sizeof(MaterialParams<R>)}, {textures.data(), textures.size() * sizeof(TextureRec<R>)},
+                {cs.lights.data(), cs.lights.size() * sizeof(LightRec)}};
+            auto pack = [&](const int (&order)[ST_COUNT], SmallLayout& L, const char** out) -> int {
+                std::vector<char> blob;
+                for (int k : order) {
+                    const size_t off = (blob.size() + 15) & ~size_t(15);
+                    blob.resize(off + tbl[k].bytes);
+                    if (tbl[k].bytes) std::memcpy(blob.data() + off, tbl[k].data, tbl[k].bytes);
+                    L.begin[k] = uint32_t(off);
+                    L.end[k] = uint32_t(off + tbl[k].bytes);
+                }
+                blob.resize((blob.size() + 15) & ~size_t(15));
+                L.total_bytes = uint32_t(blob.size());
+                return buf.upload(blob, out);
             };
-            SmallLayout& L = view.lay;
-            L.ops = put(cs.ops.data(), cs.ops.size() * sizeof(Op));
-            L.bounds = put(bounds.data(), bounds.size() * sizeof(Bounds<R>));
-            L.chain_offsets = put(cs.chain_offsets.data(), cs.chain_offsets.size() * 4);
-            L.chain_items = put(cs.chain_items.data(), cs.chain_items.size() * 4);
-            L.xforms = put(xforms.data(), xforms.size() * sizeof(Xform<R>));
-            L.spheres = put(spheres.data(), spheres.size() * sizeof(SpherePrim<R>));
-            L.planes = put(planes.data(), planes.size() * sizeof(PlanePrim<R>));
-            L.suns = put(suns.data(), suns.size() * sizeof(SunPrim<R>));
-            L.meshes = put(cs.meshes.data(), cs.meshes.size() * sizeof(MeshInst));
-            L.materials = put(cs.materials.data(), cs.materials.size() * sizeof(MaterialRec));
-            L.material_params = put(mparams.data(), mparams.size() * sizeof(MaterialParams<R>));
-            L.textures = put(textures.data(), textures.size() * sizeof(TextureRec<R>));
-            L.lights = put(cs.lights.data(), cs.lights.size() * sizeof(LightRec));
-            blob.resize((blob.size() + 15) & ~size_t(15));
-            L.total_bytes = uint32_t(blob.size());
-            if ((st = buf.upload(blob, &view.small_blob)) != RT_OK) return st;
+            const int order_prims[ST_COUNT] = {ST_OPS, ST_CHAIN_OFFSETS, ST_CHAIN_ITEMS, ST_XFORMS, ST_MESHES, ST_SUNS, ST_PLANES, ST_BOUNDS, ST_SPHERES,
+                                               ST_MATERIALS, ST_MATERIAL_PARAMS, ST_LIGHTS, ST_TEXTURES};
+            const int order_shade[ST_COUNT] = {ST_OPS, ST_CHAIN_OFFSETS, ST_CHAIN_ITEMS, ST_XFORMS, ST_MESHES, ST_SUNS, ST_LIGHTS, ST_PLANES, ST_MATERIALS,
+                                               ST_MATERIAL_PARAMS, ST_TEXTURES, ST_SPHERES, ST_BOUNDS};
+            if ((st = pack(order_prims, view.lay, &view.small_blob)) != RT_OK) return st;
+            if ((st = pack(order_shade, view.lay_shade, &view.small_blob_shade)) != RT_OK) return st;
         }
         view.n_lights = cs.n_top_lights;
         view.lights_is_list = cs.lights_is_list;
@@ -503,7 +521,6 @@ struct RtScene {
         void* pool_dev = nullptr;      // the same descriptor in device memory (k_wf_shade re-reads the array bases from it)
         uint32_t* queue[2] = {nullptr, nullptr};
         uint32_t* mesh_queue = nullptr;
-        rt::SampleCtr* d_sctr = nullptr;   // sample counters of the current replica group (k_wf_shade restarts)
         void* mesh_spill = nullptr;        // k_wf_mesh: stack levels beyond the LDS part
         size_t mesh_spill_bytes = 0;
         rt::WfCounters* d_ctr = nullptr;
@@ -647,14 +664,12 @@ int wf_ensure(RtScene* s, uint32_t capacity) {
         if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->depth))) return st;
         if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->hpc))) return st;
         if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->htri))) return st;
-        if (int st = alloc((size_t(capacity) / 64 + 1) * 4, reinterpret_cast<void**>(&pool->qcur))) return st;
         for (int q = 0; q < 2; q++) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.queue[q]), size_t(capacity) * 4));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.mesh_queue), size_t(capacity) * 4));
         HIP_TRY(hipMalloc(&w.pool_dev, sizeof(WfPool<R>)));
         HIP_TRY(hipMemcpy(w.pool_dev, pool, sizeof(WfPool<R>), hipMemcpyHostToDevice));
         if (!w.d_ctr) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.d_ctr), sizeof(WfCounters)));
         if (!w.h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w.h_ctr), sizeof(WfCounters)));
-        if (!w.d_sctr) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.d_sctr), sizeof(SampleCtr) * kSampleCounters));
         if (w.events.empty()) {
             w.events.resize(136);  // 4 per iteration, up to 32 iterations between host checks, + 2 for the stand-alone prims launch
             for (auto& e : w.events) e = nullptr;
@@ -736,15 +751,22 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     if (vol) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_intersect<R, false, true>, 256, lds));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_intersect<R, false, false>, 256, lds));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
-    // Scenes whose program has exactly one mesh op use the split intersect (k_wf_prims + k_wf_mesh); scenes
-    // without any mesh need k_wf_prims alone.
-    int32_t mesh_pc = -1;
-    int n_mesh_ops = 0;
-    for (size_t i = 0; i < s->compiled.ops.size(); i++)
-        if (s->compiled.ops[i].type == OP_MESH) { n_mesh_ops++; mesh_pc = int32_t(i); }
-    if (n_mesh_ops != 1 || env_u32("RT_WF_SPLIT", 1) == 0 || vol) mesh_pc = -1;  // a volume's draws happen in program order
-    const bool prims_only = n_mesh_ops == 0 && env_u32("RT_WF_SPLIT", 1) != 0 && !vol;
-    const bool split = mesh_pc >= 0;
+    // The split intersect: k_wf_prims for the spheres / quads / sky / sun (and the volumes they bound) and, when the program has
+    // mesh ops (any number of instances), k_wf_mesh for those.  Scenes it does not cover use the combined kernel
+    // (k_wf_intersect): a mesh inside a volume's boundary, or in front of a volume in program order (the volume's free-flight
+    // draw depends on the closest hit so far, volume.rs:40-43, so that mesh cannot be deferred).  RT_WF_SPLIT=0 (tests):
+    // the combined kernel for every scene.
+    const int n_mesh_ops = int(s->compiled.mesh_ops.size());
+    bool vol_split_ok = true;
+    if (vol) {
+        int32_t last_vol = -1;
+        for (size_t i = 0; i < s->compiled.ops.size(); i++)
+            if (s->compiled.ops[i].type == OP_VOL_END) last_vol = int32_t(i);
+        vol_split_ok = n_mesh_ops == 0 || s->compiled.mesh_ops.front() > last_vol;
+    }
+    const bool use_split = env_u32("RT_WF_SPLIT", 1) != 0 && vol_split_ok && n_mesh_ops < 32767;  // k_wf_mesh packs the mesh-op index in 15 bits
+    const bool prims_only = use_split && n_mesh_ops == 0;
+    const bool split = use_split && n_mesh_ops > 0;
     // k_wf_mesh keeps (child, entry distance) pairs: a shallow LDS part (occupancy) + a global spill part
     // BVH node format of k_wf_mesh: 1 = 4-wide quantised (BvhNode4q, 64 B, default), 0 = 4-wide f32 (BvhNode4f, 128 B; A/B control).
     // An 8-wide quantised node (a third fewer visits) was slower: profiles/r02/ab/node_width_and_size.txt.
@@ -774,14 +796,32 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     const uint32_t refill_min = env_u32("RT_WF_REFILL", 32);  // measured optimum (64 = no refill: -20 %)
     const uint32_t inner_min = env_u32("RT_WF_INNER_MIN", 16);
     // small tables staged in LDS by the prims / shade kernels when they fit
-    const bool lds_tables = ds.view.lay.total_bytes <= 48u * 1024u && env_u32("RT_LDS_TABLES", 1) != 0;
-    const size_t lds_small = lds_tables ? size_t(ds.view.lay.total_bytes) : 0;
+    // small tables staged in LDS by the prims / shade kernels: the longest prefix of whole tables (in the kernel's own table order)
+    // that fits the budget; 32 KB keeps four workgroups per CU resident next to the queue lists
+    const bool lds_tables = env_u32("RT_LDS_TABLES", 1) != 0;
+    const uint32_t lds_budget = env_u32("RT_LDS_BUDGET", 32u * 1024u);
+    auto staged_prefix = [&](const SmallLayout& L) -> uint32_t {
+        if (!lds_tables) return 0u;
+        if (L.total_bytes <= lds_budget) return L.total_bytes;
+        uint32_t best = 0;  // tables are packed back to back in staging order: a table fits iff its end does
+        for (int k = 0; k < ST_COUNT; k++) {
+            bool prefix_ok = L.end[k] <= lds_budget;
+            if (prefix_ok && L.end[k] > best) {
+                // every table that starts before this one ends must fit as well (it does: ends are monotone along the order)
+                best = L.end[k];
+            }
+        }
+        return (best + 15u) & ~15u;
+    };
+    const uint32_t staged_prims = staged_prefix(ds.view.lay), staged_shade = staged_prefix(ds.view.lay_shade);
+    const int lds_prims = staged_prims == 0 ? 0 : (staged_prims == ds.view.lay.total_bytes ? 1 : 2);          // kernel variant: none / all / prefix
+    // k_wf_shade: all or nothing (a staged prefix read through flat instructions was 3 % slower than global memory on the default scene)
+    const int lds_shade = (staged_shade != 0 && staged_shade == ds.view.lay_shade.total_bytes) ? 1 : (env_u32("RT_LDS_SHADE_PREFIX", 0) && staged_shade ? 2 : 0);
     const bool iter_log = env_u32("RT_WF_ITER_LOG", 0) != 0;
     const bool trace_pool = env_u32("RT_WF_TRACE", 0) != 0;  // debug: dump the first pool slots after every iteration
     const uint32_t check_every = trace_pool ? 1u : std::min<uint32_t>(32u, std::max<uint32_t>(1u, env_u32("RT_WF_CHECK", 8)));  // 4 timing events per iteration, 128 events
     const bool tex = s->compiled.needs_tex_interpreter;
     const size_t shade_lds_pad = env_u32("RT_WF_SHADE_LDS_PAD", 0);  // experiments: fewer resident blocks of the shade kernel
-    const uint32_t reserve_pct = std::min<uint32_t>(100u, env_u32("RT_WF_RESERVE_PCT", 6));  // share of the restarts served by the shared sample counters
 
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
@@ -803,34 +843,23 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
         grp.strata = strata;
         if (grp.total >= (1ull << 51)) return set_err(RT_E_UNSUPPORTED, "more than 2^51 samples in one replica group");
         uint32_t first = uint32_t(std::min<uint64_t>(capacity, grp.total));
-        // private quotas of the groups of 64 slots: all but `reserve_pct` percent of the samples that k_wf_generate does not
-        // start; the rest goes through the shared counters (rt_wavefront.h, SampleCtr)
-        grp.quota_base = first;
-        grp.quota_groups = first / 64;
-        grp.quota = 0;
-        if (grp.quota_groups > 0 && reserve_pct < 100) {
-            const uint64_t q = uint64_t(double(grp.total - first) * (1.0 - 0.01 * double(reserve_pct)) / double(grp.quota_groups));
-            grp.quota = uint32_t(std::min<uint64_t>(q, 1ull << 31));
-        }
-        const uint64_t shared_from = grp.quota_base + uint64_t(grp.quota_groups) * grp.quota;
-        HIP_TRY(hipMemsetAsync(pool.qcur, 0, (size_t(first) / 64 + 1) * 4, stream));
         pool.capacity = first;  // slots in use by this group: the kernels address slots directly while all of them are queued
         WfCounters init{};
         init.n_in = first;
         init.n_out = 0;
         init.cursor = 0;
         init.n_mesh = 0;
-        init.dry_mask = 0;
+        init.next_sample = first;
         *w.h_ctr = init;
         HIP_TRY(hipMemcpyAsync(w.d_ctr, w.h_ctr, sizeof(WfCounters), hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(k_wf_init_samples, dim3(1), dim3(64), 0, stream, w.d_sctr, shared_from, uint64_t(grp.total), w.d_ctr);
         hipLaunchKernelGGL((k_wf_generate<R>), dim3((first + 255) / 256), dim3(256), 0, stream, pool, first, grp, cv, pv, w.queue[0]);
         int qi = 0;
         uint32_t upper = first;  // upper bound of the queue length (never grows: slots are reused in place)
-#define RT_LAUNCH_PRIMS(ST, L) hipLaunchKernelGGL((k_wf_prims<R, ST, L>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), lds_small + (WF_CHUNK + 4) * 4, stream, ds.view, pool, w.queue[qi], w.mesh_queue, w.d_ctr, s->d_counters, mesh_pc)
-#define RT_LAUNCH_PRIMS_ANY() do { if (stats) { if (lds_tables) RT_LAUNCH_PRIMS(true, true); else RT_LAUNCH_PRIMS(true, false); } \
-                                   else { if (lds_tables) RT_LAUNCH_PRIMS(false, true); else RT_LAUNCH_PRIMS(false, false); } } while (0)
-#define RT_LAUNCH_MESH_V(ST, ND, QUEUE, NPTR, CPTR) hipLaunchKernelGGL((k_wf_mesh<R, ST, ND>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, QUEUE, w.d_ctr, s->d_counters, refill_min, inner_min, mesh_pc, static_cast<uint2*>(w.mesh_spill), lds_levels, NPTR, CPTR)
+#define RT_LAUNCH_PRIMS(ST, L, VL) hipLaunchKernelGGL((k_wf_prims<R, ST, L, VL>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), (L ? size_t(staged_prims) : size_t(0)) + (WF_CHUNK + 4) * 4, stream, ds.view, pool, w.queue[qi], w.mesh_queue, w.d_ctr, s->d_counters, staged_prims)
+#define RT_LAUNCH_PRIMS_ANY() do { if (vol) { if (stats) RT_LAUNCH_PRIMS(true, 0, true); else RT_LAUNCH_PRIMS(false, 0, true); } \
+                                   else if (stats) { if (lds_prims == 1) RT_LAUNCH_PRIMS(true, 1, false); else if (lds_prims == 2) RT_LAUNCH_PRIMS(true, 2, false); else RT_LAUNCH_PRIMS(true, 0, false); } \
+                                   else { if (lds_prims == 1) RT_LAUNCH_PRIMS(false, 1, false); else if (lds_prims == 2) RT_LAUNCH_PRIMS(false, 2, false); else RT_LAUNCH_PRIMS(false, 0, false); } } while (0)
+#define RT_LAUNCH_MESH_V(ST, ND, QUEUE, NPTR, CPTR) hipLaunchKernelGGL((k_wf_mesh<R, ST, ND>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, QUEUE, w.d_ctr, s->d_counters, refill_min, inner_min, static_cast<uint2*>(w.mesh_spill), lds_levels, NPTR, CPTR)
 #define RT_LAUNCH_MESH(QUEUE, NPTR, CPTR)                                                                                                         \
     do {                                                                                                                                          \
         if (stats) { if (node_kind == 1) RT_LAUNCH_MESH_V(true, 1, QUEUE, NPTR, CPTR); else RT_LAUNCH_MESH_V(true, 0, QUEUE, NPTR, CPTR); } \
@@ -838,9 +867,8 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     } while (0)
         for (;;) {
             size_t ev = 0;
-            // near the end of the last group (a sample counter has run dry: the others follow within a few percent of the
-            // render) the host looks after every second iteration, so that the tail is seen when it starts
-            const bool near_end = s->tail_flag && t0 + nrep >= T && w.h_ctr->dry_mask != 0ull;
+            // near the end of the last group the host looks after every second iteration, so that the tail is seen when it starts
+            const bool near_end = s->tail_flag && t0 + nrep >= T && w.h_ctr->next_sample + 4ull * pool.capacity >= grp.total;
             const uint32_t check_now = near_end ? std::min<uint32_t>(check_every, 2u) : check_every;
             for (uint32_t k = 0; k < check_now; k++) {
                 HIP_TRY(hipEventRecord(w.events[ev++], stream));
@@ -857,11 +885,11 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
 #undef RT_LAUNCH_ISECT
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 }
-#define RT_LAUNCH_SHADE(ST, L, TX) hipLaunchKernelGGL((k_wf_shade<R, ST, L, TX>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), (L ? lds_small : size_t(0)) + (WF_CHUNK + 4) * 4 + shade_lds_pad, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.d_sctr, w.sample_L, s->d_counters, static_cast<const WfPool<R>*>(w.pool_dev))
+#define RT_LAUNCH_SHADE(ST, L, TX) hipLaunchKernelGGL((k_wf_shade<R, ST, L, TX>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), (L ? size_t(staged_shade) : size_t(0)) + (2 * WF_CHUNK + 8) * 4 + shade_lds_pad, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters, static_cast<const WfPool<R>*>(w.pool_dev), staged_shade)
                 if (tex) {  // interpreter variant: tables from global memory (rare scenes, fewer instantiations)
-                    if (stats) RT_LAUNCH_SHADE(true, false, true); else RT_LAUNCH_SHADE(false, false, true);
-                } else if (stats) { if (lds_tables) RT_LAUNCH_SHADE(true, true, false); else RT_LAUNCH_SHADE(true, false, false); }
-                else { if (lds_tables) RT_LAUNCH_SHADE(false, true, false); else RT_LAUNCH_SHADE(false, false, false); }
+                    if (stats) RT_LAUNCH_SHADE(true, 0, true); else RT_LAUNCH_SHADE(false, 0, true);
+                } else if (stats) { if (lds_shade == 1) RT_LAUNCH_SHADE(true, 1, false); else if (lds_shade == 2) RT_LAUNCH_SHADE(true, 2, false); else RT_LAUNCH_SHADE(true, 0, false); }
+                else { if (lds_shade == 1) RT_LAUNCH_SHADE(false, 1, false); else if (lds_shade == 2) RT_LAUNCH_SHADE(false, 2, false); else RT_LAUNCH_SHADE(false, 0, false); }
 #undef RT_LAUNCH_SHADE
                 hipLaunchKernelGGL(k_wf_advance, dim3(1), dim3(1), 0, stream, w.d_ctr);
                 HIP_TRY(hipEventRecord(w.events[ev++], stream));
@@ -919,6 +947,17 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+#ifdef RT_SHADE_STAMPS
+    {
+        unsigned long long h[16];
+        HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_shade_stamps), sizeof h));
+        const double trips = double(h[8] ? h[8] : 1);
+        const char* names[7] = {"loop head / previous trip's tail", "state loads + resolve_hit", "throughput / rng loads + shade_hit", "stores + list appends",
+                                "barrier after phase 1", "phase 2 (restarts)", "barrier + phase 3 (queue)"};
+        std::fprintf(stderr, "[k_wf_shade stamps] %llu waves, %llu wave-trips (cumulative over the process)\n", h[9], h[8]);
+        for (int k = 0; k < 7; k++) std::fprintf(stderr, "  %-40s %10.0f clk per wave-trip\n", names[k], double(h[k]) / trips);
+    }
+#endif
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     DeviceCounters hc{};
@@ -1032,7 +1071,6 @@ void rt_scene_destroy(RtScene* s) {
     rt::wf_release_pool(s->wf);
     if (s->wf.mesh_spill) (void)hipFree(s->wf.mesh_spill);
     if (s->wf.d_ctr) (void)hipFree(s->wf.d_ctr);
-    if (s->wf.d_sctr) (void)hipFree(s->wf.d_sctr);
     if (s->wf.h_ctr) (void)hipHostFree(s->wf.h_ctr);
     if (s->wf.sample_L) (void)hipFree(s->wf.sample_L);
     if (s->wf.acc) (void)hipFree(s->wf.acc);

@@ -86,10 +86,22 @@ struct MeshInst {
     uint32_t flags;      // RT_MESH_* | MESH_HAS_UV
     uint32_t n_tris;
     uint32_t max_depth;
-    uint32_t node4_base;  // first BvhNode4f of this mesh in nodes4[]
+    uint32_t node4_base;  // root of this mesh's 4-wide BVH in nodes4[] / nodes4q[] (their child references are absolute)
     uint32_t _pad;
 };
 constexpr uint32_t MESH_HAS_UV = 0x100u;
+
+// What k_wf_mesh needs to enter mesh op m of the scene program (SceneView::mesh_op_recs[m], program order), in one record:
+// the kernel enters one mesh op at a time for all the lanes that wait for it, so the record is read with scalar loads.
+template <typename R>
+struct alignas(16) MeshOpRec {
+    int32_t pc;           // the OP_MESH op
+    int32_t chain;        // its transform chain (Op::chain)
+    uint32_t node4_base;  // root of the mesh's 4-wide BVH
+    uint32_t flags;       // MeshInst::flags
+    R lo[3], hi[3];       // SceneView::mesh_bounds of the instance
+};
+
 
 // BVH2 node: the two children's boxes live in the parent, so one fetch decides both.
 // child >= 0: inner node index (relative to node_base); child < 0: leaf,
@@ -108,7 +120,7 @@ struct alignas(sizeof(R) == 8 ? 128 : 64) BvhNode {
 // hit is ever skipped.  Used by the wavefront mesh kernel for both arithmetic types.
 struct alignas(128) BvhNode4f {
     float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
-    int32_t child[4];  // >= 0 inner node (relative to node4_base), < 0 leaf code, kEmptyChild
+    int32_t child[4];  // >= 0 inner node (ABSOLUTE index into nodes4), < 0 leaf: ~child = (first triangle slot, absolute, << 3) | (count - 1); kEmptyChild
     uint32_t _pad[4];
 };
 
@@ -185,12 +197,18 @@ struct LightRec {
 };
 constexpr int32_t kLightListShift = 20;
 
-// All the small tables (everything except BVH nodes, triangle records and attributes) are ALSO
-// uploaded as one contiguous blob, so that a workgroup can stage them in LDS with one cooperative
-// copy and walk the scene program / materials / lights without global-memory round trips.
+// All the small tables (everything except BVH nodes, triangle records and attributes) are ALSO uploaded as contiguous
+// blobs, so that a workgroup can stage them in LDS with one cooperative copy and walk the scene program / materials /
+// lights without global-memory round trips.  Two blobs, the same tables in two orders: what k_wf_prims reads most first
+// (ops, chains, transforms, boxes, primitives) and what k_wf_shade reads most first (ops, chains, transforms, materials,
+// lights, textures, primitives).  A kernel stages a PREFIX of whole tables (as much as its LDS budget allows: the default
+// scene's 455 spheres, each with its own material and texture, make 90 KB of tables) and reads the rest from global memory.
+enum SmallTable : int {
+    ST_OPS, ST_BOUNDS, ST_CHAIN_OFFSETS, ST_CHAIN_ITEMS, ST_XFORMS, ST_SPHERES, ST_PLANES, ST_SUNS, ST_MESHES, ST_MATERIALS,
+    ST_MATERIAL_PARAMS, ST_TEXTURES, ST_LIGHTS, ST_COUNT
+};
 struct SmallLayout {
-    uint32_t ops, bounds, chain_offsets, chain_items, xforms, spheres, planes, suns, meshes, materials,
-        material_params, textures, lights;  // byte offsets, 16-B aligned
+    uint32_t begin[ST_COUNT], end[ST_COUNT];  // byte range of every table inside the blob (begin 16-B aligned)
     uint32_t total_bytes;
 };
 
@@ -211,6 +229,9 @@ struct SceneView {
     const BvhNode4f* nodes4;       // 4-wide f32 nodes (k_wf_mesh with RT_WF_NODES=0: A/B control)
     const BvhNode4q* nodes4q;      // the same nodes, quantised to 64 B (k_wf_mesh)
     const Bounds<R>* mesh_bounds;  // per mesh instance: exact box of its triangles (object space)
+    const int32_t* mesh_ops;       // pcs of the OP_MESH ops in program order: k_wf_prims defers them, k_wf_mesh serves them one after the other
+    const MeshOpRec<R>* mesh_op_recs;  // the same ops as k_wf_mesh wants them
+    int32_t n_mesh_ops;
     const TriRec<R>* tris;
     const TriAttr<R>* attrs;
     const MaterialRec* materials;
@@ -225,8 +246,10 @@ struct SceneView {
     int32_t stop_on_zero_weight;  // CompiledScene::zero_weight_stop: a path whose throughput is exactly 0 may end (rt_device.h, path_goes_on)
     int32_t stack_entries;   // per-lane LDS traversal stack size
     int32_t n_ops;
-    const char* small_blob;  // the tables above packed per SmallLayout (global memory)
+    const char* small_blob;        // the small tables packed in k_wf_prims' order (global memory)
     SmallLayout lay;
+    const char* small_blob_shade;  // ... and in k_wf_shade's order
+    SmallLayout lay_shade;
 };
 
 template <typename R>

@@ -40,7 +40,6 @@ struct WfPool {
     uint32_t* depth;                 // remaining depth (the `depth` argument of ray_color)
     R *ht, *hu, *hv;                 // closest hit: t, (u, v)
     int32_t *hpc, *htri;             // op that produced it (-1 none), triangle slot
-    uint32_t* qcur;                  // per 64 consecutive slots: samples taken from that group's private quota (WfGroup::quota)
 };
 
 // Element `slot` of a pool array through a 32-bit BYTE offset.  `base + zext(offset)` lets the compiler address every
@@ -64,29 +63,7 @@ struct WfCounters {
     uint32_t n_out;       // entries appended to the next queue
     uint32_t cursor;      // next queue entry to hand out (persistent intersect / mesh kernel)
     uint32_t n_mesh;      // entries of the mesh queue (paths whose ray enters a deferred mesh's box)
-    unsigned long long dry_mask;  // bit k: sample counter k has handed out its whole range (all ones: no sample left to start)
-};
-
-// Samples that have not been started yet are handed out in two tiers, so that k_wf_shade can restart a finished path IN
-// PLACE, in the trip that shaded it, without waiting for anything:
-//  1. a PRIVATE QUOTA per 64 consecutive pool slots (WfGroup::quota, ~94 % of the samples): while the whole pool is alive
-//     those 64 slots are always handled by one wave in one trip, which reads the group's cursor (WfPool::qcur) with the
-//     path state and writes it back: no atomic, no extra round trip.  (A returning atomic add per wave and trip - the first
-//     form of this kernel - cost 37 % of its time: the wave's only memory round trip per trip became two.)
-//  2. K shared counters for the rest, each over its own contiguous range of sample indices and on its own 128-byte line:
-//     one returning atomic add per wave that needs samples its quota no longer has.  One word sustains ~83 such atomics
-//     per microsecond, 64 words ~3200 (tools/ubench/atomic_rate.hip, profiles/r03/ubench_atomic_rate.txt).  A wave starts
-//     at counter (wave index mod K) and moves on for good when a counter runs dry; the wave whose add crosses the end of a
-//     range records it in WfCounters::dry_mask.  Groups consume their quotas at the same rate within a few percent, so the
-//     shared tier is what the fast groups live on until the slow ones are done.
-// In the tail of a render (pool no longer full: slots are compacted, a wave's lanes belong to different groups) a lane
-// takes what is left of its group's quota with a per-lane atomic.  Which sample a slot gets does not matter for the frame:
-// every sample owns its slot of the per-sample radiance buffer.
-constexpr uint32_t kSampleCounters = 64;
-struct alignas(128) SampleCtr {
-    unsigned long long next;  // next sample index to hand out (runs past `hi` once dry)
-    unsigned long long hi;    // end of this counter's range
-    unsigned long long _pad[14];
+    unsigned long long next_sample;  // next sample (within the group) to start
 };
 
 // Sample s of a replica group -> (replica, stratum, owned pixel).  Pixels run fastest so that a
@@ -99,11 +76,6 @@ struct WfGroup {
     double inv_per_replica, inv_npix, inv_width;  // reciprocals rounded to nearest: quotient ESTIMATES, made exact in div_by
     uint32_t tid0;         // first replica of the group
     uint32_t strata;       // S*S
-    // Unrendered samples are handed out in two tiers (see SampleCtr): every 64 consecutive pool slots own a private
-    // quota of `quota` samples starting at quota_base + (slot / 64) * quota, the rest is shared through the counters.
-    uint64_t quota_base;   // first sample index of the quotas = samples started by k_wf_generate
-    uint32_t quota;        // samples per group of 64 slots (0: none)
-    uint32_t quota_groups; // groups that have a quota (the complete ones: capacity / 64)
 };
 
 // floor(a / b) and the remainder for a < 2^51: the reciprocal estimate is off by at most one, the remainder test makes it
@@ -150,19 +122,6 @@ __global__ void __launch_bounds__(256) k_wf_generate(WfPool<R> pool, uint32_t co
     at(pool.sample, i) = uint64_t(i);
     at(pool.depth, i) = cam.max_depth;
     queue[i] = i;
-}
-
-// The K sample counters of a replica group: samples [0, first) are started by k_wf_generate, counter k owns an equal share
-// of [first, total).
-__global__ void k_wf_init_samples(SampleCtr* sctr, uint64_t first, uint64_t total, WfCounters* ctr) {
-    const uint32_t k = threadIdx.x;
-    if (k >= kSampleCounters) return;
-    const uint64_t rest = total - first;
-    const uint64_t lo = first + rest * k / kSampleCounters, hi = first + rest * (k + 1) / kSampleCounters;
-    sctr[k].next = lo;
-    sctr[k].hi = hi;
-    unsigned long long dry = __ballot(lo >= hi);
-    if (k == 0) ctr->dry_mask = dry;
 }
 
 // Number of lanes below `lane` whose bit is set in `mask` (v_mbcnt_lo/hi).
@@ -475,24 +434,31 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<
 }
 
 // ---------------------------------------------------------------------------------------------
-// Split intersect for scenes with ONE mesh instance (all BASELINE configs):
+// Split intersect (every scene without volumes; any number of mesh instances):
 //   k_wf_prims  every lane runs the same scene program over spheres / quads / sky / sun (uniform
-//               control flow); the mesh op is deferred: paths whose object-space ray enters the
-//               mesh's root box with the interval left by the other primitives are appended
-//               (ballot + prefix sum) to the mesh queue.
+//               control flow); the mesh ops are deferred: paths whose object-space ray enters a
+//               mesh's root box with the interval left by the primitives visited so far are appended
+//               (ballot + prefix sum) to the mesh queue, once.
 //   k_wf_mesh   persistent waves that do nothing but BVH traversal, "while-while": all lanes
 //               descend inner nodes until each holds a leaf, then all test triangles; idle lanes
-//               are refilled from the mesh queue.
+//               are refilled from the mesh queue.  A lane serves the mesh ops of its path one after the
+//               other, in program order (SceneView::mesh_ops), with the interval the earlier ones left.
 // Closest-hit semantics are those of the in-order program: the nearest t wins and, at exactly equal
 // t, the op that comes first in the reference's visiting order (its tests use strict `t < closest`).
 // ---------------------------------------------------------------------------------------------
-// The scene program over everything except the (single) deferred mesh op: closest hit of `wray` with the spheres /
-// quads / sky / sun in `best`; returns true if the ray also has to visit the mesh (its object-space ray enters the
-// mesh's box inside the interval the other primitives left).  Uniform control flow over the wave: every lane
-// walks the same program.
-template <typename R, bool STATS>
-RT_DEV bool prims_search(const SceneView<R>& sc, const Ray<R>& wray, int32_t mesh_pc, Best<R>& best, LaneCounters& cnt) {
-    const R t_lo = R(0.001);
+// The scene program over everything except the deferred mesh ops: closest hit of `wray` with the spheres /
+// quads / sky / sun in `best`; returns true if the ray also has to visit a mesh (its object-space ray enters a
+// mesh's box inside the interval the primitives visited before it left).  Every lane walks the same program.
+// VOL: the program contains volumes (OP_VOL_*: two boundary searches, then the free-flight draw from the path's RNG,
+// volume.rs:33-71, as in world_test / k_wf_intersect) whose boundaries are made of spheres and quads, and every mesh op
+// comes AFTER the last volume: a volume's draw depends on the closest hit so far (volume.rs:40-43), so a mesh in front
+// of it cannot be deferred (such scenes, and meshes inside a boundary, use the combined kernel).
+template <typename R, bool STATS, bool VOL = false>
+RT_DEV bool prims_search(const SceneView<R>& sc, const Ray<R>& wray, Best<R>& best, LaneCounters& cnt, Rng* rng = nullptr) {
+    const R t_lo_outer = R(0.001);
+    R t_lo = t_lo_outer;     // changes only inside a volume's boundary searches
+    Best<R> saved{};         // VOL: the caller's search state during a boundary search
+    R vol_enter = R(0);
     Ray<R> cur = wray;
     best.t = Lim<R>::inf(); best.pc = -1; best.tri = -1; best.u = R(0); best.v = R(0);
     bool to_mesh = false;
@@ -502,6 +468,54 @@ RT_DEV bool prims_search(const SceneView<R>& sc, const Ray<R>& wray, int32_t mes
         const Op op = sc.ops[pc];
         if (op.type == OP_END) break;
         switch (op.type) {
+            case OP_VOL_BEGIN:  // volume.rs:34: boundary.test(ray, Interval::UNIVERSE)
+                if constexpr (VOL) {
+                    saved = best;
+                    best.t = Lim<R>::inf();
+                    best.pc = -1;
+                    t_lo = -Lim<R>::inf();
+                }
+                break;
+            case OP_VOL_MID:  // volume.rs:35-37: second search over (t_enter + 0.0001, inf)
+                if constexpr (VOL) {
+                    if (best.pc < 0) {
+                        best = saved;
+                        t_lo = t_lo_outer;
+                        pc = op.skip;
+                        continue;
+                    }
+                    vol_enter = best.t;
+                    t_lo = vol_enter + R(0.0001);
+                    best.t = Lim<R>::inf();
+                    best.pc = -1;
+                }
+                break;
+            case OP_VOL_END:  // volume.rs:38-68
+                if constexpr (VOL) {
+                    const bool has_exit = best.pc >= 0;
+                    const R t_exit = best.t;
+                    best = saved;
+                    t_lo = t_lo_outer;
+                    if (has_exit) {
+                        R t_min = fmax(vol_enter, t_lo_outer);
+                        R t_max = fmin(t_exit, best.t);
+                        if (!(t_min >= t_max)) {
+                            t_min = fmax(t_min, R(0));
+                            R ray_len = length(cur.d);
+                            R dist_inside = (t_max - t_min) * ray_len;
+                            R uu = rng_uniform<R>(*rng);
+                            R hit_dist = sc.volumes[op.arg].neg_inv_density * (uu == R(0) ? -Lim<R>::inf() : log_r(uu));
+                            if (!(hit_dist > dist_inside)) {
+                                best.t = t_min + hit_dist / ray_len;
+                                best.pc = pc;
+                                best.tri = -1;
+                                best.u = R(0);
+                                best.v = R(0);
+                            }
+                        }
+                    }
+                }
+                break;
             case OP_BOUNDS:
                 if (!test_bounding_box(sc.bounds[op.arg], cur, t_lo, best.t)) {
                     pc = op.skip;
@@ -528,7 +542,7 @@ RT_DEV bool prims_search(const SceneView<R>& sc, const Ray<R>& wray, int32_t mes
                 if (plane_test<R, true>(sc.planes[op.arg], cur, t_lo, best.t, t, u, v) && hit_takes_over(sc, t, op, best)) { best.t = t; best.pc = pc; best.u = u; best.v = v; }
                 break;
             }
-            case OP_MESH: {  // deferred (pc == mesh_pc: the only mesh op of this program)
+            case OP_MESH: {  // deferred to k_wf_mesh
                 // Does the ray enter the mesh's box inside (t_lo, best.t]?  Decided HERE, with the closest hit so far (ops behind
                 // the mesh can only shorten the interval, and the test only culls: conservative), so that no copy of the
                 // object-space ray has to stay alive to the end of the program.
@@ -545,7 +559,7 @@ RT_DEV bool prims_search(const SceneView<R>& sc, const Ray<R>& wray, int32_t mes
                 R tn = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmax(fmin(t0z, t1z), t_lo));
                 R tf = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmin(fmax(t0z, t1z), best.t));
                 tf = tf + fabs(tf) * eps;
-                to_mesh = (tn <= tf) && rb.lo[0] <= rb.hi[0];
+                to_mesh = to_mesh || ((tn <= tf) && rb.lo[0] <= rb.hi[0]);
                 break;
             }
             case OP_SKY:
@@ -572,17 +586,19 @@ RT_DEV bool prims_search(const SceneView<R>& sc, const Ray<R>& wray, int32_t mes
 #ifndef RT_PRIMS_WAVES
 #define RT_PRIMS_WAVES 5  // 95 VGPRs without scratch since the mesh-box test moved to the mesh op (round 2); 4 waves before: 171 -> 157 ms per step
 #endif
-template <typename R, bool STATS, bool LDS>
-__global__ void __launch_bounds__(256, RT_PRIMS_WAVES) k_wf_prims(SceneView<R> sc_g, WfPool<R> pool, const uint32_t* __restrict__ queue,
+// LDS: 0 = tables in global memory, 1 = all small tables staged in LDS, 2 = a prefix of them (see scene_tables_to_lds)
+template <typename R, bool STATS, int LDS, bool VOL>
+__global__ void __launch_bounds__(256, VOL ? 3 : RT_PRIMS_WAVES) k_wf_prims(SceneView<R> sc_g, WfPool<R> pool, const uint32_t* __restrict__ queue,
                                                   uint32_t* __restrict__ mesh_queue, WfCounters* __restrict__ ctr,
-                                                  DeviceCounters* counters, int32_t mesh_pc) {
+                                                  DeviceCounters* counters, uint32_t staged) {
     extern __shared__ __align__(16) char lds_raw[];
     uint32_t* mesh_list = reinterpret_cast<uint32_t*>(lds_raw);  // [WF_CHUNK]
     uint32_t* lc = mesh_list + WF_CHUNK;                        // [0] list length, [1] queue base
     char* tables = reinterpret_cast<char*>(lc + 4);
     if (threadIdx.x < 4) lc[threadIdx.x] = 0;
     SceneView<R> sc = sc_g;
-    if constexpr (LDS) sc = scene_tables_to_lds(sc_g, tables);
+    if constexpr (LDS == 1) sc = scene_tables_to_lds<R, true>(sc_g, sc_g.lay, sc_g.small_blob, tables, staged);
+    else if constexpr (LDS == 2) sc = scene_tables_to_lds<R, false>(sc_g, sc_g.lay, sc_g.small_blob, tables, staged);
     else __syncthreads();
     const uint32_t n = ctr->n_in;
     const bool full = n == pool.capacity;
@@ -597,7 +613,14 @@ __global__ void __launch_bounds__(256, RT_PRIMS_WAVES) k_wf_prims(SceneView<R> s
             slot = full ? i : queue[i];
             const Ray<R> wray = make_ray(mk<R>(at(pool.ox, slot), at(pool.oy, slot), at(pool.oz, slot)), mk<R>(at(pool.dx, slot), at(pool.dy, slot), at(pool.dz, slot)));
             Best<R> best;
-            to_mesh = prims_search<R, STATS>(sc, wray, mesh_pc, best, cnt);
+            if constexpr (VOL) {  // Volume::test draws the free-flight distance from the path's stream (volume.rs:47)
+                Rng rng;
+                rng.s = at(pool.rng, slot);
+                to_mesh = prims_search<R, STATS, true>(sc, wray, best, cnt, &rng);
+                at(pool.rng, slot) = rng.s;
+            } else {
+                to_mesh = prims_search<R, STATS>(sc, wray, best, cnt);
+            }
             at(pool.ht, slot) = best.t; at(pool.hu, slot) = best.u; at(pool.hv, slot) = best.v;
             at(pool.hpc, slot) = best.pc; at(pool.htri, slot) = best.tri;
         }
@@ -659,10 +682,10 @@ template <typename R> constexpr uint32_t kMeshWaveLds = 1024u + 3u * 64u * uint3
 template <typename R, bool STATS, int NODE>
 __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc, WfPool<R> pool, const uint32_t* __restrict__ mesh_queue,
                                                                  WfCounters* __restrict__ ctr, DeviceCounters* counters,
-                                                                 uint32_t refill_min, uint32_t inner_min, int32_t mesh_pc,
+                                                                 uint32_t refill_min, uint32_t inner_min,
                                                                  uint2* __restrict__ spill, int lds_levels,
                                                                  const uint32_t* __restrict__ n_ptr, uint32_t* __restrict__ cursor_ptr) {
-    // n_ptr / cursor_ptr: length and hand-out cursor of `mesh_queue` (&ctr->n_mesh / &ctr->cursor, or the fallback queue's)
+    // n_ptr / cursor_ptr: length and hand-out cursor of `mesh_queue` (&ctr->n_mesh / &ctr->cursor)
     extern __shared__ uint2 lds_stack2[];
     MeshStack stk;
     stk.lds = (LdsU64*)(lds_stack2 + threadIdx.x);
@@ -678,41 +701,47 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
     stk.spill_stride = gridDim.x * blockDim.x;
     const uint32_t n = *n_ptr;
     const R t_lo = R(0.001);
-    const Op mop = sc.ops[mesh_pc];
-    const MeshInst mi = sc.meshes[mop.arg];
-    const Bounds<R> rb = sc.mesh_bounds[mop.arg];
-    const BvhNode4f* nodes = sc.nodes4 + mi.node4_base;
-    const BvhNode4q* nodesq = sc.nodes4q + mi.node4_base;
-    const TriRec<R>* tris = sc.tris + mi.tri_base;
-    const bool hit_back = (mi.flags & RT_MESH_HIT_BACK_FACES) != 0;
+    const BvhNode4f* nodes = sc.nodes4;     // child references and leaf triangle slots are absolute: one table for every mesh
+    const BvhNode4q* nodesq = sc.nodes4q;
+    const TriRec<R>* tris = sc.tris;
+    const uint32_t n_mesh_ops = uint32_t(sc.n_mesh_ops);
     const R big = sizeof(R) == 8 ? R(1e150) : R(1e18);
-
+    const MeshOpRec<R>* mrecs = sc.mesh_op_recs;
     LaneCounters cnt;
     uint32_t w_node = 0, w_tri = 0, w_refill = 0, l_refill = 0, l_culled = 0;  // STATS: see DeviceCounters
-    bool has = false;
+    bool has = false;        // this lane is inside a mesh's BVH
+    bool pending = false;    // this lane holds a path whose mesh op `mcur` has not been entered yet
     bool exhausted = false;
-    bool found = false;      // a triangle closer than the other primitives' hit was found
     WaveRange range;
     uint32_t slot = 0;
+    // bits 0-14: index into sc.mesh_ops of the mesh being traversed / tried next; bits 15-29: 1 + index of the mesh op that holds
+    // the closest triangle found for this path so far (0: none); bit 31: the current mesh hits back faces
+    uint32_t mcur = 0;
     V3<R> o{}, d{};          // object-space ray, exact: used by the triangle tests
     R t_max = R(0), hit_u = R(0), hit_v = R(0), t_shift = R(0);
     int32_t hit_tri = -1;
     // f32 culling ray: origin moved onto the mesh box (so |origin| <= mesh extent), t measured from there
     float ivx = 0.f, ivy = 0.f, ivz = 0.f, oix = 0.f, oiy = 0.f, oiz = 0.f, tmax32 = 0.f;
-    uint32_t nearx = 0, neary = 1, nearz = 2;  // float4 index of the near plane array per axis (lo: 0,1,2 / hi: 3,4,5)
     int32_t node = 0;        // >= 0 inner node, < 0 leaf
     int sp = 0;
 
+    // The lane has finished every mesh of its path: the closest triangle, if one beat the other primitives' hit, is the path's hit.
+    auto finish_path = [&]() {
+        const uint32_t hm = (mcur >> 15) & 0x7FFFu;
+        if (hm != 0u) {
+            at(pool.ht, slot) = t_max; at(pool.hu, slot) = hit_u; at(pool.hv, slot) = hit_v;
+            at(pool.hpc, slot) = sc.mesh_ops[hm - 1u]; at(pool.htri, slot) = hit_tri;
+        }
+    };
     // Pops entries until one whose box can still contain a closer hit is found (entry distance <= current
-    // bound); a lane whose stack runs empty has finished and writes its hit.
+    // bound); a lane whose stack runs empty has finished this mesh and goes on to the path's next mesh op.
     auto pop_next = [&]() {
         for (;;) {
             if (sp == 0) {
                 has = false;
-                if (found) {
-                    at(pool.ht, slot) = t_max; at(pool.hu, slot) = hit_u; at(pool.hv, slot) = hit_v;
-                    at(pool.hpc, slot) = mesh_pc; at(pool.htri, slot) = hit_tri;
-                }
+                mcur = (mcur & 0x7FFFFFFFu) + 1u;
+                if ((mcur & 0x7FFFu) < n_mesh_ops) pending = true;
+                else finish_path();
                 return;
             }
             sp--;
@@ -726,57 +755,89 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
     };
 
     for (;;) {
-        // ---- refill ----
-        unsigned long long idle = __ballot(!has);
-        uint32_t n_idle = uint32_t(__popcll(idle));
-        if (!exhausted && n_idle >= refill_min) {
-            uint32_t my = 0;
-            if (STATS) w_refill++;
-            if (wave_fetch(range, idle, cursor_ptr, n, exhausted, my)) {
-                if (STATS) l_refill++;
-                slot = mesh_queue[my];
-                Ray<R> wray = make_ray(mk<R>(at(pool.ox, slot), at(pool.oy, slot), at(pool.oz, slot)), mk<R>(at(pool.dx, slot), at(pool.dy, slot), at(pool.dz, slot)));
-                Ray<R> ray = ray_in_chain(sc, wray, mop.chain);
-                o = ray.o;
-                d = ray.d;
-                V3<R> inv = {fabs(ray.inv.x) > big ? copysign(big, ray.inv.x) : ray.inv.x,
-                             fabs(ray.inv.y) > big ? copysign(big, ray.inv.y) : ray.inv.y,
-                             fabs(ray.inv.z) > big ? copysign(big, ray.inv.z) : ray.inv.z};
-                // entry into the mesh box (>= 0); the culling origin is o + d * t_shift
-                R e0x = (rb.lo[0] - o.x) * inv.x, e1x = (rb.hi[0] - o.x) * inv.x;
-                R e0y = (rb.lo[1] - o.y) * inv.y, e1y = (rb.hi[1] - o.y) * inv.y;
-                R e0z = (rb.lo[2] - o.z) * inv.z, e1z = (rb.hi[2] - o.z) * inv.z;
-                t_shift = fmax(fmax(fmin(e0x, e1x), fmin(e0y, e1y)), fmax(fmin(e0z, e1z), R(0)));
-                if (!(t_shift < Lim<R>::inf())) t_shift = R(0);
-                V3<R> oc = o + d * t_shift;
-                const float big32 = 1e18f;
-                float dx32 = float(d.x), dy32 = float(d.y), dz32 = float(d.z);
-                ivx = 1.0f / dx32; ivy = 1.0f / dy32; ivz = 1.0f / dz32;
-                ivx = fabsf(ivx) > big32 ? copysignf(big32, ivx) : ivx;
-                ivy = fabsf(ivy) > big32 ? copysignf(big32, ivy) : ivy;
-                ivz = fabsf(ivz) > big32 ? copysignf(big32, ivz) : ivz;
-                oix = float(oc.x) * ivx; oiy = float(oc.y) * ivy; oiz = float(oc.z) * ivz;
-                // with lo <= hi the nearer plane of an axis is `lo` for a non-negative inverse direction, `hi`
-                // otherwise: lo * iv vs hi * iv are then already ordered and the per-box min/max disappear
-                nearx = ivx < 0.0f ? 3u : 0u;
-                neary = ivy < 0.0f ? 4u : 1u;
-                nearz = ivz < 0.0f ? 5u : 2u;
-                // The other primitives' closest hit bounds the search.  At exactly equal t the op that
-                // comes first in program order wins: if that is the mesh, t == bound must be accepted.
-                R bound = at(pool.ht, slot);
-                int32_t bpc = at(pool.hpc, slot);
-                t_max = (bpc > mesh_pc && bound < Lim<R>::inf()) ? nextafter(bound, Lim<R>::inf()) : bound;
-                tmax32 = f32_at_least(t_max - t_shift);
-                found = false;
-                hit_tri = -1;
-                node = 0;
-                sp = 0;
-                has = true;
-                if (STATS) cnt.mesh_rays++;
+        // ---- refill: lanes without a path take a queue entry; lanes between two meshes of their path enter the next one ----
+        const unsigned long long idle = __ballot(!has);
+        const unsigned long long waiting = __ballot(pending);
+        if ((uint32_t(__popcll(idle)) >= refill_min && (!exhausted || waiting != 0ull)) || (waiting != 0ull && idle == ~0ull)) {
+            const unsigned long long want = __ballot(!has && !pending);
+            if (!exhausted && want != 0ull) {
+                uint32_t my = 0;
+                if (STATS) w_refill++;
+                if (wave_fetch(range, want, cursor_ptr, n, exhausted, my)) {
+                    if (STATS) l_refill++;
+                    slot = mesh_queue[my];
+                    mcur = 0;
+                    hit_tri = -1;
+                    pending = true;
+                }
+            }
+            // Enter the path's next mesh: its object-space ray against the mesh's box, inside the interval that the other
+            // primitives (k_wf_prims) and the meshes visited before left.  Lanes whose ray misses the box try the op after it.
+            // One mesh op per trip - the one the first waiting lane wants - so that its record, transform chain and matrices
+            // are wave-uniform: scalar loads into SGPRs, as when the kernel served a single mesh.  (Per-lane records cost
+            // every refill four dependent vector-memory round trips: +8 % on the whole kernel.)
+            for (;;) {
+                const unsigned long long pend = __ballot(pending);
+                if (pend == 0ull) break;
+                const uint32_t m = uint32_t(__builtin_amdgcn_readfirstlane(int(__shfl(int(mcur & 0x7FFFu), __ffsll((long long)pend) - 1))));
+                MeshOpRec<R> rb;  // wave-uniform: scalar loads into SGPRs (field by field: no copy constructor from an address space)
+                {
+                    const auto* rec = as_const_mem(mrecs) + m;
+                    rb.pc = rec->pc; rb.chain = rec->chain; rb.node4_base = rec->node4_base; rb.flags = rec->flags;
+#pragma unroll
+                    for (int a = 0; a < 3; a++) { rb.lo[a] = rec->lo[a]; rb.hi[a] = rec->hi[a]; }
+                }
+                if (pending && (mcur & 0x7FFFu) == m) {
+                    const int32_t mpc = rb.pc;
+                    Ray<R> wray = make_ray(mk<R>(at(pool.ox, slot), at(pool.oy, slot), at(pool.oz, slot)), mk<R>(at(pool.dx, slot), at(pool.dy, slot), at(pool.dz, slot)));
+                    Ray<R> ray = ray_in_chain_uniform(sc, wray, rb.chain);
+                    o = ray.o;
+                    d = ray.d;
+                    V3<R> inv = {fabs(ray.inv.x) > big ? copysign(big, ray.inv.x) : ray.inv.x,
+                                 fabs(ray.inv.y) > big ? copysign(big, ray.inv.y) : ray.inv.y,
+                                 fabs(ray.inv.z) > big ? copysign(big, ray.inv.z) : ray.inv.z};
+                    // The other primitives' closest hit bounds the search.  At exactly equal t the op that comes first in
+                    // program order wins: if that is this mesh, t == bound must be accepted.  A triangle of an EARLIER mesh
+                    // always wins a tie (strict bound, like the reference's shrinking interval: list.rs:58-74).
+                    const R bound = at(pool.ht, slot);
+                    const int32_t bpc = at(pool.hpc, slot);
+                    const R excl = (bpc > mpc && bound < Lim<R>::inf()) ? nextafter(bound, Lim<R>::inf()) : bound;
+                    t_max = ((mcur >> 15) & 0x7FFFu) != 0u ? fmin(t_max, excl) : excl;
+                    // entry into the mesh box (>= 0) and exit; the culling origin is o + d * t_shift
+                    R e0x = (rb.lo[0] - o.x) * inv.x, e1x = (rb.hi[0] - o.x) * inv.x;
+                    R e0y = (rb.lo[1] - o.y) * inv.y, e1y = (rb.hi[1] - o.y) * inv.y;
+                    R e0z = (rb.lo[2] - o.z) * inv.z, e1z = (rb.hi[2] - o.z) * inv.z;
+                    t_shift = fmax(fmax(fmin(e0x, e1x), fmin(e0y, e1y)), fmax(fmin(e0z, e1z), R(0)));
+                    R t_exit = fmin(fmin(fmax(e0x, e1x), fmax(e0y, e1y)), fmax(e0z, e1z));
+                    // a miss only if it is one with a few ulps of slack on both ends (a NaN compares false: the mesh is entered)
+                    const R eps = Lim<R>::eps() * R(16);
+                    const bool miss = (t_shift - fabs(t_shift) * eps > t_exit + fabs(t_exit) * eps) || (t_shift - fabs(t_shift) * eps > t_max) || !(rb.lo[0] <= rb.hi[0]);
+                    if (miss) {
+                        mcur++;
+                        if ((mcur & 0x7FFFu) >= n_mesh_ops) { pending = false; finish_path(); }
+                    } else {
+                        if (!(t_shift < Lim<R>::inf())) t_shift = R(0);
+                        V3<R> oc = o + d * t_shift;
+                        const float big32 = 1e18f;
+                        float dx32 = float(d.x), dy32 = float(d.y), dz32 = float(d.z);
+                        ivx = 1.0f / dx32; ivy = 1.0f / dy32; ivz = 1.0f / dz32;
+                        ivx = fabsf(ivx) > big32 ? copysignf(big32, ivx) : ivx;
+                        ivy = fabsf(ivy) > big32 ? copysignf(big32, ivy) : ivy;
+                        ivz = fabsf(ivz) > big32 ? copysignf(big32, ivz) : ivz;
+                        oix = float(oc.x) * ivx; oiy = float(oc.y) * ivy; oiz = float(oc.z) * ivz;
+                        tmax32 = f32_at_least(t_max - t_shift);
+                        node = int32_t(rb.node4_base);
+                        sp = 0;
+                        if (rb.flags & RT_MESH_HIT_BACK_FACES) mcur |= 0x80000000u;
+                        has = true;
+                        pending = false;
+                        if (STATS) cnt.mesh_rays++;
+                    }
+                }
             }
         }
         if (__ballot(has) == 0ull) {
-            if (exhausted) break;
+            if (exhausted && __ballot(pending) == 0ull) break;
             continue;
         }
         // ---- inner nodes: descend until (nearly) every lane holds a leaf or has finished ----
@@ -799,7 +860,9 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
                     ch[0] = cc.x; ch[1] = cc.y; ch[2] = cc.z; ch[3] = cc.w;
                     const float ax = __uint_as_float(h0.w) * ivx, ay = __uint_as_float(h1.x) * ivy, az = __uint_as_float(h1.y) * ivz;
                     const float bx = fmaf(__uint_as_float(h0.x), ivx, -oix), by = fmaf(__uint_as_float(h0.y), ivy, -oiy), bz = fmaf(__uint_as_float(h0.z), ivz, -oiz);
-                    const bool negx = nearx != 0u, negy = neary != 1u, negz = nearz != 2u;
+                    // with lo <= hi the nearer plane of an axis is `lo` for a non-negative inverse direction, `hi` otherwise:
+                    // lo * iv vs hi * iv are then already ordered and the per-box min/max disappear
+                    const bool negx = ivx < 0.0f, negy = ivy < 0.0f, negz = ivz < 0.0f;
                     const uint32_t qnx = negx ? h2.y : h1.z, qfx = negx ? h1.z : h2.y;
                     const uint32_t qny = negy ? h2.z : h1.w, qfy = negy ? h1.w : h2.z;
                     const uint32_t qnz = negz ? h2.w : h2.x, qfz = negz ? h2.x : h2.w;
@@ -814,6 +877,7 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
                     }
                 } else {
                     const float4* nd = reinterpret_cast<const float4*>(nodes + node);
+                    const uint32_t nearx = ivx < 0.0f ? 3u : 0u, neary = ivy < 0.0f ? 4u : 1u, nearz = ivz < 0.0f ? 5u : 2u;  // float4 index of the near planes
                     const float4 nx = nd[nearx], fx = nd[3u - nearx];
                     const float4 ny = nd[neary], fy = nd[5u - neary];
                     const float4 nz = nd[nearz], fz = nd[7u - nearz];
@@ -883,7 +947,9 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
                     const uint32_t k = e >> 8;
                     const V3<R> po = {__shfl(o.x, owner), __shfl(o.y, owner), __shfl(o.z, owner)};
                     const V3<R> pd = {__shfl(d.x, owner), __shfl(d.y, owner), __shfl(d.z, owner)};
-                    const uint32_t pfirst = uint32_t(__shfl(int(first), owner));
+                    const uint32_t pfirst_hb = uint32_t(__shfl(int(first | (mcur & 0x80000000u)), owner));  // bit 31: the owner's mesh hits back faces
+                    const uint32_t pfirst = pfirst_hb & 0x7FFFFFFFu;
+                    const bool hit_back = (pfirst_hb >> 31) != 0u;
                     R rt = Lim<R>::inf(), ru = R(0), rv = R(0);  // t = +inf: "no hit" (fails `t_max <= t` at the owner)
                     if (act) {
                         const TriRec<R>& tr = tris[pfirst + k];
@@ -917,8 +983,8 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
                             const R t = res_t[idx];
                             if (t <= t_lo || t_max <= t) continue;
                             t_max = t; hit_u = res_u[idx]; hit_v = res_v[idx];
-                            hit_tri = int32_t(mi.tri_base + first + uint32_t(j));
-                            found = true;
+                            hit_tri = int32_t(first + uint32_t(j));
+                            mcur = (mcur & 0xC0007FFFu) | (((mcur & 0x7FFFu) + 1u) << 15);
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -957,54 +1023,34 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
 #endif
 #define RT_SHADE_BOUNDS __launch_bounds__(256, TEX ? 1 : RT_SHADE_WAVES)
 
-// Sample indices for the lanes in `m` (the wave's finished paths), in lane order: ONE returning atomic add per wave on the
-// wave's current counter; a counter that cannot serve the whole request serves what it has left and the wave moves on to
-// the next one for good.  Returns ~0 in lanes that get none (every counter is dry: the render is in its tail).
-// k: the wave's current counter (wave-uniform, kept across calls); dry: WfCounters::dry_mask as this wave knows it.
-RT_DEV unsigned long long wave_reserve_samples(SampleCtr* __restrict__ sctr, WfCounters* __restrict__ ctr, uint32_t& k, unsigned long long& dry,
-                                               unsigned long long m) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n = uint32_t(__popcll(m));
-    const uint32_t rank = lane_prefix(m);
-    const int leader = __ffsll((long long)m) - 1;
-    const bool mine = ((m >> lane) & 1ull) != 0ull;
-    unsigned long long s = ~0ull;
-    uint32_t got = 0;
-    while (got < n && dry != ~0ull) {
-        if ((dry >> k) & 1ull) {  // known to be dry: next counter
-            k = (k + 1u) % kSampleCounters;
-            continue;
-        }
-        const uint32_t want = n - got;
-        unsigned long long old = 0;
-        if (int(lane) == leader) old = atomicAdd(&sctr[k].next, (unsigned long long)want);
-        old = __shfl(old, leader);
-        const unsigned long long hi = sctr[k].hi;
-        const uint32_t avail = old < hi ? uint32_t(min((unsigned long long)want, hi - old)) : 0u;
-        if (mine && rank >= got && rank < got + avail) s = old + (rank - got);
-        got += avail;
-        if (old + want >= hi) {  // this request reached the end of the range
-            dry |= 1ull << k;
-            // exactly one request CROSSES the end: that wave publishes it (one atomic per counter and render, not per wave)
-            if (old < hi && int(lane) == leader) atomicOr(&ctr->dry_mask, 1ull << k);
-            k = (k + 1u) % kSampleCounters;
-        }
-    }
-    return s;
-}
+// Diagnostic build (-DRT_SHADE_STAMPS, tools/gpu_shade_stamps.sh): where a wave of k_wf_shade spends its cycles.  s_memtime stamps
+// around the sections of a trip, summed per wave and added to g_shade_stamps at the end; never compiled into the product.
+#ifdef RT_SHADE_STAMPS
+__device__ unsigned long long g_shade_stamps[16];
+#define RT_STAMP(k)                                                     \
+    do {                                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+        stamp_acc[k] += now_ - stamp_t;                                 \
+        stamp_t = now_;                                                 \
+    } while (0)
+#else
+#define RT_STAMP(k) do { } while (0)
+#endif
 
-template <typename R, bool STATS, bool LDS, bool TEX>
+template <typename R, bool STATS, int LDS, bool TEX>
 __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam, ParamsView<R> prm, WfPool<R> pool, WfGroup<R> grp,
                                            const uint32_t* __restrict__ queue_in, uint32_t* __restrict__ queue_out,
-                                           WfCounters* __restrict__ ctr, SampleCtr* __restrict__ sctr, double* __restrict__ sample_L,
-                                           DeviceCounters* counters, const WfPool<R>* __restrict__ pool_dev) {
+                                           WfCounters* __restrict__ ctr, double* __restrict__ sample_L, DeviceCounters* counters,
+                                           const WfPool<R>* __restrict__ pool_dev, uint32_t staged) {
     extern __shared__ __align__(16) char lds_raw[];
     uint32_t* alive_list = reinterpret_cast<uint32_t*>(lds_raw);  // [WF_CHUNK] slots that go to the next queue
-    uint32_t* lc = alive_list + WF_CHUNK;                        // [0] n_alive [1] queue base
-    char* tables = reinterpret_cast<char*>(lc + 4);
-    if (threadIdx.x < 4) lc[threadIdx.x] = 0;
+    uint32_t* dead_list = alive_list + WF_CHUNK;                 // [WF_CHUNK] slots whose path ended
+    uint32_t* lc = dead_list + WF_CHUNK;                         // [0] n_alive [1] n_dead [2,3] sample base [4] queue base
+    char* tables = reinterpret_cast<char*>(lc + 8);
+    if (threadIdx.x < 8) lc[threadIdx.x] = 0;
     SceneView<R> sc = sc_g;
-    if constexpr (LDS) sc = scene_tables_to_lds(sc_g, tables);
+    if constexpr (LDS == 1) sc = scene_tables_to_lds<R, true>(sc_g, sc_g.lay_shade, sc_g.small_blob_shade, tables, staged);
+    else if constexpr (LDS == 2) sc = scene_tables_to_lds<R, false>(sc_g, sc_g.lay_shade, sc_g.small_blob_shade, tables, staged);
     else __syncthreads();
     const uint32_t n = ctr->n_in;
     // While samples remain every finished path restarts in place, so ALL slots are queued: the order of
@@ -1014,33 +1060,20 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
     const uint32_t begin = blockIdx.x * WF_CHUNK;
     const uint32_t end = min(n, begin + WF_CHUNK);
     LaneCounters cnt;
-    // sample counters: the wave's home counter and what is known to be dry (a relaxed device-scope load: other waves publish
-    // crossings while this kernel runs; a stale value costs one more atomic, never a sample)
-    uint32_t sk = (blockIdx.x * 4u + (threadIdx.x >> 6)) % kSampleCounters;
-    unsigned long long dry = __hip_atomic_load(&ctr->dry_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // One path vertex per lane, chunk by chunk.  A lane whose path ends stores the sample's radiance and starts the next
-    // unrendered sample IN PLACE, in the same trip: every lane then writes ONE complete state - its continuation or its new
-    // camera ray - so the 64 slots of a wave fill whole 128-byte lines of every pool array with one store instruction each.
-    // (Round 2 restarted the finished slots of a workgroup together in a second phase: the lines of a trip were written in two
-    // parts, 70 % of the lanes and later the other 30 %, and left the L2 in between: 1.8 x the bytes on the write side,
-    // profiles/r02/c4_f64 vs profiles/r03/c4_f64.)
+#ifdef RT_SHADE_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- phase 1: one path vertex per lane, chunk by chunk ----
     for (uint32_t base = begin; base < end; base += blockDim.x) {
         const uint32_t i = base + threadIdx.x;
         const bool active = i < end;
         bool alive = false;
         uint32_t slot = 0;
-        PathState<R> ps;
-        ps.ray = make_ray(mk<R>(0, 0, 0), mk<R>(0, 0, 0));
-        ps.throughput = mk<R>(0, 0, 0);
-        ps.radiance = mk<R>(0, 0, 0);
-        ps.depth = 0;
-        Rng rng;
-        rng.s = 0;
-        // the quota cursor of the wave's 64 slots travels with the path state: loaded here, used after the shading
-        uint32_t qc = 0;
-        if (full && ((base + (threadIdx.x & ~63u)) >> 6) < grp.quota_groups) qc = at(pool.qcur, (base + (threadIdx.x & ~63u)) >> 6);
+        RT_STAMP(0);
         if (active) {
             slot = full ? i : queue_in[i];
+            PathState<R> ps;
             ps.ray = make_ray(mk<R>(at(pool.ox, slot), at(pool.oy, slot), at(pool.oz, slot)), mk<R>(at(pool.dx, slot), at(pool.dy, slot), at(pool.dz, slot)));
             Best<R> best;
             best.t = at(pool.ht, slot); best.u = at(pool.hu, slot); best.v = at(pool.hv, slot);
@@ -1050,8 +1083,11 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
             HitInfo<R> hit{};
             if (best.pc >= 0) hit = resolve_hit<R, TEX>(sc, ps.ray, best);
             asm volatile("" ::: "memory");
+            RT_STAMP(1);
             ps.throughput = mk<R>(at(pool.tr, slot), at(pool.tg, slot), at(pool.tb, slot));
+            ps.radiance = mk<R>(0, 0, 0);
             ps.depth = at(pool.depth, slot);
+            Rng rng;
             rng.s = at(pool.rng, slot);
             bool cont;
             if (best.pc < 0) {  // camera.rs:331 background
@@ -1061,74 +1097,89 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
                 cont = shade_hit<R, STATS, TEX>(sc, prm, ps, hit, rng, cnt);
             }
             ps.depth--;
-            if (cont && ps.depth != 0) {  // depth == 0: ray_color returns black without tracing (camera.rs:290)
-                alive = true;
-            } else {
+            RT_STAMP(2);
+            // The array bases are re-read HERE from a copy of the pool descriptor in global memory (scalar loads): with
+            // the kernel-argument copy the compiler kept the eleven load addresses alive as VGPR pairs across the
+            // whole shading code to reuse them for these stores (22 VGPRs of a kernel that is occupancy-bound).
+            asm volatile("" ::: "memory");
+            const WfPool<R>& pw = *pool_dev;
+            alive = cont && ps.depth != 0;  // depth == 0: ray_color returns black without tracing (camera.rs:290)
+            if (!alive) {
                 if (cont) end_black(ps);  // depth exhausted: the next ray_color call returns black (camera.rs:290)
                 uint64_t s = at(pool.sample, slot);
                 sample_L[3 * s + 0] = double(ps.radiance.x);
                 sample_L[3 * s + 1] = double(ps.radiance.y);
                 sample_L[3 * s + 2] = double(ps.radiance.z);
-            }
-        }
-        // The array bases are re-read HERE from a copy of the pool descriptor in global memory (scalar loads): with
-        // the kernel-argument copy the compiler kept the eleven load addresses alive as VGPR pairs across the
-        // whole shading code to reuse them for these stores (22 VGPRs of a kernel that is occupancy-bound).
-        asm volatile("" ::: "memory");
-        const WfPool<R>& pw = *pool_dev;
-        const bool is_dead = active && !alive;
-        unsigned long long dead = __ballot(is_dead);
-        if (dead != 0ull) {
-            unsigned long long s2 = ~0ull;
-            // tier 1: the private quota of this group of 64 slots
-            if (full) {
-                const uint32_t g = (base + (threadIdx.x & ~63u)) >> 6;  // wave-uniform: the wave's 64 slots are one group
-                if (g < grp.quota_groups && qc < grp.quota) {
-                    const uint32_t take = min(uint32_t(__popcll(dead)), grp.quota - qc);
-                    const uint32_t rank = lane_prefix(dead);
-                    if (is_dead && rank < take) s2 = grp.quota_base + uint64_t(g) * grp.quota + qc + rank;
-                    if ((threadIdx.x & 63u) == 0) pool.qcur[g] = qc + take;
-                }
-            } else if (is_dead) {
-                const uint32_t g = slot >> 6;
-                if (g < grp.quota_groups && at(pool.qcur, g) < grp.quota) {  // the cursor only grows: a stale value costs one atomic
-                    const uint32_t c = atomicAdd(&pool.qcur[g], 1u);
-                    if (c < grp.quota) s2 = grp.quota_base + uint64_t(g) * grp.quota + c;
-                }
-            }
-            // tier 2: the shared counters
-            dead = __ballot(is_dead && s2 == ~0ull);
-            if (dead != 0ull && dry != ~0ull) {
-                const unsigned long long s3 = wave_reserve_samples(sctr, ctr, sk, dry, dead);
-                if (s2 == ~0ull) s2 = s3;
-            }
-            if (is_dead && s2 != ~0ull) {
-                V3<R> o, d;
-                wf_new_sample(s2, grp, cam, prm, o, d, rng);
-                ps.ray.o = o;
-                ps.ray.d = d;
+                // This slot restarts in phase 2 on a new camera sample.  The part of that state which does not depend on the
+                // sample is stored HERE, by the same store instructions as the surviving lanes' values: those arrays then get
+                // their 128-byte lines whole in one go.  (Round 2 wrote every array in two parts - 70 % of a line's slots
+                // here, the rest in phase 2 after the line had left the L2 - and the L2 wrote back 1.8 x the bytes;
+                // profiles/r03/ab/shade_inplace_restart.txt has the counters and why the remaining arrays stay split.)
                 ps.throughput = mk<R>(1, 1, 1);
                 ps.depth = cam.max_depth;
-                put_global(pw.sample, slot, (uint64_t)s2);
-                alive = true;
+                if (!cam.has_aperture) ps.ray.o = ld3(cam.position);  // camera.rs:265-275: the origin moves only with an aperture
+            }
+            put_global(pw.tr, slot, ps.throughput.x); put_global(pw.tg, slot, ps.throughput.y); put_global(pw.tb, slot, ps.throughput.z);
+            put_global(pw.depth, slot, ps.depth);
+            if (alive || !cam.has_aperture) { put_global(pw.ox, slot, ps.ray.o.x); put_global(pw.oy, slot, ps.ray.o.y); put_global(pw.oz, slot, ps.ray.o.z); }
+            if (alive) {
+                put_global(pw.dx, slot, ps.ray.d.x); put_global(pw.dy, slot, ps.ray.d.y); put_global(pw.dz, slot, ps.ray.d.z);
+                put_global(pw.rng, slot, rng.s);
             }
         }
-        if (alive) {
-            put_global(pw.ox, slot, ps.ray.o.x); put_global(pw.oy, slot, ps.ray.o.y); put_global(pw.oz, slot, ps.ray.o.z);
-            put_global(pw.dx, slot, ps.ray.d.x); put_global(pw.dy, slot, ps.ray.d.y); put_global(pw.dz, slot, ps.ray.d.z);
-            put_global(pw.tr, slot, ps.throughput.x); put_global(pw.tg, slot, ps.throughput.y); put_global(pw.tb, slot, ps.throughput.z);
-            put_global(pw.rng, slot, rng.s);
-            put_global(pw.depth, slot, ps.depth);
-        }
-        lds_append(alive, slot, alive_list, &lc[0]);
+        lds_append(active && alive, slot, alive_list, &lc[0]);
+        lds_append(active && !alive, slot, dead_list, &lc[1]);
+        RT_STAMP(3);
     }
     __syncthreads();
-    // ---- surviving slots -> next queue (one global atomic per workgroup, coalesced copy) ----
-    const uint32_t n_alive = lc[0];
-    if (threadIdx.x == 0 && n_alive) lc[1] = atomicAdd(&ctr->n_out, n_alive);
+    RT_STAMP(4);
+    // ---- phase 2: finished paths restart IN PLACE on the next samples (one global atomic per workgroup; all lanes generate
+    //      camera rays together, compacted over the workgroup: run inside phase 1 by the dead lanes themselves this code
+    //      executes at 20-30 % lane utilisation in every trip and costs more than the split write saves) ----
+    const uint32_t n_dead = lc[1];
+    if (threadIdx.x == 0 && n_dead) {
+        unsigned long long b0 = atomicAdd(&ctr->next_sample, (unsigned long long)n_dead);
+        lc[2] = uint32_t(b0);
+        lc[3] = uint32_t(b0 >> 32);
+    }
     __syncthreads();
-    const uint32_t qb = lc[1];
+    const unsigned long long s_base = (unsigned long long)lc[2] | ((unsigned long long)lc[3] << 32);
+    for (uint32_t j0 = 0; j0 < n_dead; j0 += blockDim.x) {
+        const uint32_t j = j0 + threadIdx.x;
+        bool restarted = false;
+        uint32_t slot = 0;
+        if (j < n_dead) {
+            const unsigned long long s2 = s_base + j;
+            slot = dead_list[j];
+            if (s2 < grp.total) {
+                V3<R> o, d;
+                Rng rng;
+                wf_new_sample(s2, grp, cam, prm, o, d, rng);
+                if (cam.has_aperture) { at(pool.ox, slot) = o.x; at(pool.oy, slot) = o.y; at(pool.oz, slot) = o.z; }
+                at(pool.dx, slot) = d.x; at(pool.dy, slot) = d.y; at(pool.dz, slot) = d.z;
+                at(pool.rng, slot) = rng.s;
+                at(pool.sample, slot) = uint64_t(s2);
+                restarted = true;
+            }
+        }
+        lds_append(restarted, slot, alive_list, &lc[0]);
+    }
+    RT_STAMP(5);
+    __syncthreads();
+    // ---- phase 3: surviving slots -> next queue (one global atomic per workgroup, coalesced copy) ----
+    const uint32_t n_alive = lc[0];
+    if (threadIdx.x == 0 && n_alive) lc[4] = atomicAdd(&ctr->n_out, n_alive);
+    __syncthreads();
+    const uint32_t qb = lc[4];
     for (uint32_t j = threadIdx.x; j < n_alive; j += blockDim.x) queue_out[qb + j] = alive_list[j];
+    RT_STAMP(6);
+#ifdef RT_SHADE_STAMPS
+    if ((threadIdx.x & 63u) == 0) {
+        for (int k = 0; k < 7; k++) atomicAdd(&g_shade_stamps[k], stamp_acc[k]);
+        atomicAdd(&g_shade_stamps[8], (unsigned long long)(begin < end ? (end - begin + 255u) / 256u : 0u));  // trips of this wave
+        atomicAdd(&g_shade_stamps[9], 1ull);
+    }
+#endif
     if (STATS) {
         uint32_t rays = cnt.rays, prims = cnt.prim_tests;
         for (int off = 32; off > 0; off >>= 1) { rays += __shfl_down(rays, off); prims += __shfl_down(prims, off); }

@@ -104,8 +104,14 @@ def test_bench_starts_its_own_ranks():
     assert len(lines) == 1
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 4 and res["value"] > 0 and res["scaling"] == "strong"
-    assert res["config"]["frames_in_flight"] == 3      # multi-GPU ranks pipeline their frames (api.FramePipeline)
+    # every N renders its timed frames one after the other by default (the N = 1 and N > 1 lines then measure the same thing) ...
+    assert res["config"]["frames_in_flight"] == 1 and res["value_basis"].startswith("single frames")
     assert "REHEARSAL" in res["config"]["partition"]
+    # ... and pipelining the frames of a sequence (api.FramePipeline) is opt-in and labelled
+    r3 = subprocess.run(cmd + ["--frames-in-flight", "3"], cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert r3.returncode == 0, r3.stdout[-3000:] + r3.stderr[-3000:]
+    res3 = json.loads([ln for ln in r3.stdout.splitlines() if ln.startswith("{")][0])
+    assert res3["n_gpus"] == 2 and res3["config"]["frames_in_flight"] == 3 and res3["value_basis"].startswith("pipelined")
     bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "3", "--steps", "1", "--no-cpu-baseline"],
                          cwd=REPO, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stdout + bad.stderr)

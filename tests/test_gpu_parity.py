@@ -523,6 +523,25 @@ def test_headline_config_rows_match_oracle(dev):
     np.testing.assert_array_equal(wider[[0, 2, 4]], gpu)
 
 
+def test_big_mesh_row_matches_oracle(dev):
+    """The headline scene with the stand-in surface tessellated four times finer (3 484 800 triangles: BVH nodes + triangle
+    records = 314 MB, beyond the 256 MB Infinity Cache; bench workload c4_3m is profiled on it): one full row through the mesh
+    (1200 px, 100 spp) against the oracle's octree over the same triangles at the f64 bar, both schedulers bit-identical."""
+    import bench
+    bench.ensure_big_dragon("c4_3m")
+    hs = api.HostScene(["build/bigmesh/cornell_dragon_3m", "-w=1200", "-s=100", "-t=1", "--seed=1"])
+    assert hs.spp == 100 and hs.desc.contents.meshes[0].n_triangles == 3484800
+    scene = api.DeviceScene(hs.desc, 0)
+    q = hs.params.copy()
+    q.band_rows, q.n_parts, q.part = 1, 1200, 640
+    gpu = scene.render(hs.camera, q)
+    ref, st = pyoracle.render(hs.desc, hs.camera, q)
+    assert st.samples == 1200 * 100
+    assert_f64_parity(gpu, ref)
+    q.pipeline = api.RT_PIPELINE_MEGAKERNEL
+    np.testing.assert_array_equal(scene.render(hs.camera, q), gpu)
+
+
 def test_c5_config_rows_of_one_rank_match_oracle(dev):
     """BASELINE.json's multi-GPU configuration C5 (cornell_dragon, 2400x2400, 4000 spp = 10 replicas x 20x20 strata,
     frame row-tiled over 8 GPUs), the share of rank 3 exactly as `bench.py --gpus 8` partitions it
