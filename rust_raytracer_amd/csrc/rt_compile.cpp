@@ -152,33 +152,26 @@ struct Compiler {
         }
     }
 
-    // Emits the SAH tree over prims[begin, end) (indices in `idx`); leaves hold one or two primitives.
-    void emit_group_tree(std::vector<GroupPrim>& prims, std::vector<uint32_t>& idx, size_t begin, size_t end, int32_t rank_base) {
+    // The SAH tree over prims[begin, end) (indices in `idx`, permuted in place); leaves hold one or two primitives.
+    struct GNode {
+        size_t begin, end;
+        int left = -1, right = -1;
         BoxD box;
-        for (int a = 0; a < 3; a++) { box.lo[a] = HUGE_VAL; box.hi[a] = -HUGE_VAL; }
+    };
+    int build_group_tree(std::vector<GroupPrim>& prims, std::vector<uint32_t>& idx, size_t begin, size_t end, std::vector<GNode>& nodes) {
+        GNode g;
+        g.begin = begin;
+        g.end = end;
+        for (int a = 0; a < 3; a++) { g.box.lo[a] = HUGE_VAL; g.box.hi[a] = -HUGE_VAL; }
         for (size_t i = begin; i < end; i++)
             for (int a = 0; a < 3; a++) {
-                box.lo[a] = std::fmin(box.lo[a], prims[idx[i]].lo[a]);
-                box.hi[a] = std::fmax(box.hi[a], prims[idx[i]].hi[a]);
+                g.box.lo[a] = std::fmin(g.box.lo[a], prims[idx[i]].lo[a]);
+                g.box.hi[a] = std::fmax(g.box.hi[a], prims[idx[i]].hi[a]);
             }
-        Bounds<double> b;
-        for (int a = 0; a < 3; a++) { b.lo[a] = box.lo[a]; b.hi[a] = box.hi[a]; }
-        out.bounds.push_back(b);
-        const size_t bounds_op = out.ops.size();
-        emit(OP_BOUNDS, int32_t(out.bounds.size()) - 1);
+        const int self = int(nodes.size());
+        nodes.push_back(g);
         const size_t n = end - begin;
-        if (n <= 2) {
-            for (size_t i = begin; i < end; i++) {
-                const GroupPrim& p = prims[idx[i]];
-                std::vector<size_t> guard_ops;
-                for (int32_t g : p.guards) { guard_ops.push_back(out.ops.size()); emit(OP_BOUNDS, g); }
-                const RtNode& nd = d.nodes[p.node];
-                if (nd.type == RT_NODE_SPHERE) emit(OP_SPHERE, sphere_index(p.node));
-                else emit(OP_PLANE, plane_index(p.node));
-                out.ops.back().skip = rank_base + p.rank_order;  // the reference's visiting order, not the emission order
-                for (size_t go : guard_ops) out.ops[go].skip = int32_t(out.ops.size());
-            }
-        } else {
+        if (n > 2) {
             // best split of the three sorted sweeps (surface area heuristic on the geometric boxes)
             auto area = [](const BoxD& x) { double dx = x.hi[0] - x.lo[0], dy = x.hi[1] - x.lo[1], dz = x.hi[2] - x.lo[2]; return dx * dy + dy * dz + dz * dx; };
             double best_cost = HUGE_VAL;
@@ -209,10 +202,60 @@ struct Compiler {
                 const double cx = prims[x].lo[best_axis] + prims[x].hi[best_axis], cy = prims[y].lo[best_axis] + prims[y].hi[best_axis];
                 return cx < cy || (cx == cy && x < y);
             });
-            emit_group_tree(prims, idx, begin, begin + best_k, rank_base);
-            emit_group_tree(prims, idx, begin + best_k, end, rank_base);
+            const int l = build_group_tree(prims, idx, begin, begin + best_k, nodes);
+            const int r = build_group_tree(prims, idx, begin + best_k, end, nodes);
+            nodes[size_t(self)].left = l;
+            nodes[size_t(self)].right = r;
+        }
+        return self;
+    }
+
+    // Op form of the tree: OP_BOUNDS with skip pointers, the primitives (behind their guard boxes) at the leaves.
+    // prim_pc[i] = pc of the op of prims[i].
+    void emit_group_ops(const std::vector<GroupPrim>& prims, const std::vector<uint32_t>& idx, const std::vector<GNode>& nodes, int ni,
+                        int32_t rank_base, std::vector<int32_t>& prim_pc) {
+        const GNode& g = nodes[size_t(ni)];
+        Bounds<double> b;
+        for (int a = 0; a < 3; a++) { b.lo[a] = g.box.lo[a]; b.hi[a] = g.box.hi[a]; }
+        out.bounds.push_back(b);
+        const size_t bounds_op = out.ops.size();
+        emit(OP_BOUNDS, int32_t(out.bounds.size()) - 1);
+        if (g.left < 0) {
+            for (size_t i = g.begin; i < g.end; i++) {
+                const GroupPrim& p = prims[idx[i]];
+                std::vector<size_t> guard_ops;
+                for (int32_t gb : p.guards) { guard_ops.push_back(out.ops.size()); emit(OP_BOUNDS, gb); }
+                const RtNode& nd = d.nodes[p.node];
+                if (nd.type == RT_NODE_SPHERE) emit(OP_SPHERE, sphere_index(p.node));
+                else emit(OP_PLANE, plane_index(p.node));
+                out.ops.back().skip = rank_base + p.rank_order;  // the reference's visiting order, not the emission order
+                prim_pc[idx[i]] = int32_t(out.ops.size()) - 1;
+                for (size_t go : guard_ops) out.ops[go].skip = int32_t(out.ops.size());
+            }
+        } else {
+            emit_group_ops(prims, idx, nodes, g.left, rank_base, prim_pc);
+            emit_group_ops(prims, idx, nodes, g.right, rank_base, prim_pc);
         }
         out.ops[bounds_op].skip = int32_t(out.ops.size());
+    }
+
+    // BVH2 form of the tree in the mesh builder's encoding (both child boxes in the parent; a leaf = positions
+    // [begin, end) of `idx`), ready for the 4-wide collapse.
+    int32_t group_bvh2(const std::vector<GNode>& nodes, int ni, BvhBuild& b2, uint32_t depth) {
+        const GNode& g = nodes[size_t(ni)];
+        if (g.left < 0) return ~int32_t((uint32_t(g.begin) << 3) | uint32_t(g.end - g.begin - 1));
+        const size_t self = b2.nodes.size();
+        b2.nodes.emplace_back();
+        if (depth + 1 > b2.max_depth) b2.max_depth = depth + 1;
+        const int32_t c0 = group_bvh2(nodes, g.left, b2, depth + 1), c1 = group_bvh2(nodes, g.right, b2, depth + 1);
+        BuildNode& n = b2.nodes[self];
+        for (int a = 0; a < 3; a++) {
+            n.lo0[a] = nodes[size_t(g.left)].box.lo[a]; n.hi0[a] = nodes[size_t(g.left)].box.hi[a];
+            n.lo1[a] = nodes[size_t(g.right)].box.lo[a]; n.hi1[a] = nodes[size_t(g.right)].box.hi[a];
+        }
+        n.c0 = c0;
+        n.c1 = c1;
+        return int32_t(self);
     }
 
     // Tries to compile the subtree under `node` as a re-built primitive group; false = compile it op by op as usual.
@@ -235,7 +278,52 @@ struct Compiler {
         for (size_t i = 0; i < idx.size(); i++) idx[i] = uint32_t(i);
         const int32_t rank_base = next_rank;
         next_rank += int32_t(prims.size());
-        emit_group_tree(prims, idx, 0, prims.size(), rank_base);
+        std::vector<GNode> nodes;
+        build_group_tree(prims, idx, 0, prims.size(), nodes);
+        // the 4-wide BVH form first (OP_GROUP in front of the op form), unless the scene already holds too many
+        BvhBuild b2;
+        const int32_t root_ref = group_bvh2(nodes, 0, b2, 0);
+        const bool wide = root_ref >= 0 && out.group_prims.size() + prims.size() < (1u << 27);
+        size_t group_op = SIZE_MAX;
+        if (wide) {
+            group_op = out.ops.size();
+            emit(OP_GROUP, int32_t(out.groups.size()));
+        }
+        std::vector<int32_t> prim_pc(prims.size(), -1);
+        emit_group_ops(prims, idx, nodes, 0, rank_base, prim_pc);
+        if (wide) {
+            out.ops[group_op].skip = int32_t(out.ops.size());
+            Bvh4Build b4 = collapse_bvh4(b2);
+            GroupRec<double> gr{};
+            gr.root = uint32_t(out.group_nodes4.size());
+            for (int a = 0; a < 3; a++) { gr.lo[a] = b4.root_lo[a]; gr.hi[a] = b4.root_hi[a]; }
+            const uint32_t prim_base = uint32_t(out.group_prims.size());
+            for (BuildNode4 nd : b4.nodes) {
+                for (int k = 0; k < 4; k++) {
+                    if (nd.child[k] == kEmptyChild) continue;
+                    if (nd.child[k] >= 0) nd.child[k] += int32_t(gr.root);
+                    else {
+                        const uint32_t code = uint32_t(~nd.child[k]);
+                        nd.child[k] = ~int32_t((((code >> 3) + prim_base) << 3) | (code & 7u));
+                    }
+                }
+                out.group_nodes4.push_back(nd);
+            }
+            for (size_t j = 0; j < idx.size(); j++) {
+                const GroupPrim& p = prims[idx[j]];
+                GroupPrimRef r{};
+                r.pc = prim_pc[idx[j]];
+                r.guard_first = int32_t(out.group_guards.size());
+                r.guard_count = int32_t(p.guards.size());
+                for (int32_t gb : p.guards) out.group_guards.push_back(gb);
+                out.group_prims.push_back(r);
+            }
+            out.groups.push_back(gr);
+            if (b4.max_stack > out.max_group_stack) out.max_group_stack = b4.max_stack;
+            if (std::getenv("RT_COMPILE_DEBUG"))
+                std::fprintf(stderr, "[rt_compile] primitive group %zu: %zu primitives, BVH2 %zu nodes (depth %u) -> %zu 4-wide nodes, stack %u\n",
+                             out.groups.size() - 1, prims.size(), b2.nodes.size(), b2.max_depth, b4.nodes.size(), b4.max_stack);
+        }
         out.n_rebuilt_groups++;
         out.n_rebuilt_prims += uint32_t(prims.size());
         return true;
@@ -407,7 +495,7 @@ struct Compiler {
         return true;
     }
 
-    bool in_volume = false;
+    int vol_depth = 0;  // volumes whose boundary is being compiled
 
     bool compile_node(uint32_t node, int depth) {
         if (status != RT_OK) return false;
@@ -457,7 +545,7 @@ struct Compiler {
             case RT_NODE_LIST:
             case RT_NODE_BVH: {
                 if (n.type == RT_NODE_BVH && n.n_children != 2) return fail(RT_E_INVALID, "bvh node needs two children");
-                if (!in_volume && try_emit_group(node, depth)) return status == RT_OK;
+                if (vol_depth == 0 && try_emit_group(node, depth)) return status == RT_OK;
                 size_t bounds_op = SIZE_MAX;
                 bool check = n.type == RT_NODE_BVH || !(n.flags & RT_LIST_DISABLE_BOUNDS_CHECK);
                 if (check) {
@@ -488,21 +576,21 @@ struct Compiler {
                 return true;  // NullObject::test never hits (null_obj.rs:17)
             case RT_NODE_VOLUME: {  // volume.rs:33-71: the boundary's sub-program is emitted twice (entry search, exit search)
                 if (n.n_children != 1) return fail(RT_E_INVALID, "volume node needs one child (its boundary)");
-                if (in_volume) return fail(RT_E_UNSUPPORTED, "a volume inside another volume's boundary is not supported");
+                if (vol_depth >= kMaxVolDepth) return fail(RT_E_UNSUPPORTED, "volumes nested more than two levels deep (a volume inside the boundary of a volume inside a boundary)");
                 if (!check_material(n.material)) return false;
                 VolumeRec<double> v{};
                 v.neg_inv_density = -1.0 / n.p[0];  // Volume::new (volume.rs:23)
                 v.material = n.material;
                 out.volumes.push_back(v);
                 const int32_t vi = int32_t(out.volumes.size()) - 1;
-                in_volume = true;
+                vol_depth++;
                 emit(OP_VOL_BEGIN, vi);
                 bool ok = compile_node(kids[0], depth + 1);
                 const size_t mid = out.ops.size();
                 emit(OP_VOL_MID, vi);
                 ok = ok && compile_node(kids[0], depth + 1);
                 emit(OP_VOL_END, vi);
-                in_volume = false;
+                vol_depth--;
                 if (!ok) return false;
                 out.ops[mid].skip = int32_t(out.ops.size());
                 return true;
@@ -618,8 +706,8 @@ struct Compiler {
             int kind = emit_texture(t, 0, 0, &max_live, &uv);
             if (!kind) return false;
             size_t count = out.textures.size() - first;
-            if (max_live > kTexStackDepth)
-                return fail(RT_E_UNSUPPORTED, "texture expression needs more than 4 live values (nest the deeper input first)");
+            if (max_live > kTexStackMax)
+                return fail(RT_E_UNSUPPORTED, "texture expression needs more than 16 live values");
             if (first >= (1u << kTexProgShift) || count >= (1u << 11)) return fail(RT_E_UNSUPPORTED, "texture programs too large");
             // kind and uv use are kept in the two top bits of the map entry's companion tables
             program_kind[t] = kind;
@@ -679,8 +767,9 @@ struct Compiler {
         return true;
     }
 
-    // One entry of the light table for `node`.  nested: the node is a member of an ObjectList inside `lights`.
-    bool light_of(uint32_t node, bool nested, LightRec* l) {
+    // One entry of the light table for `node`.  An ObjectList member becomes a LIGHT_LIST entry whose own members are
+    // placed behind (compile_light_entries): a tree of LightRecs with the reference's recursion (list.rs:80-100).
+    bool light_of(uint32_t node, LightRec* l) {
         if (node >= d.n_nodes) return fail(RT_E_INVALID, "light node index out of range");
         const RtNode& n = d.nodes[node];
         *l = LightRec{LIGHT_OTHER, 0};
@@ -689,21 +778,21 @@ struct Compiler {
             case RT_NODE_SPHERE: l->kind = LIGHT_SPHERE; l->index = sphere_index(node); break;
             case RT_NODE_SKY: l->kind = LIGHT_SKY; break;
             case RT_NODE_SUN: l->kind = LIGHT_SUN; l->index = sun_index(node); break;
-            case RT_NODE_LIST:
-                if (nested) return fail(RT_E_UNSUPPORTED, "lists nested more than one level inside `lights` are not supported");
-                l->kind = LIGHT_LIST;
-                break;
+            case RT_NODE_LIST: l->kind = LIGHT_LIST; break;
             default: break;  // Transform / mesh / bvh / volume / null: pdf_value 0, random (1,0,0)
         }
         return l->index >= 0;
     }
 
-    bool compile_light_entries(const uint32_t* nodes, uint32_t count) {
-        // top-level entries first (lights_pdf_value / lights_random index them directly), members of nested lists behind
+    // Places the entries of one ObjectList (its members, contiguous) and, behind them, recursively the members of every
+    // member that is itself a list.  depth = nesting level of this list inside `lights` (the kernels evaluate nested
+    // pdf_value sums on an explicit stack of kMaxLightDepth frames).
+    bool compile_light_entries(const uint32_t* nodes, uint32_t count, int depth) {
+        if (depth >= kMaxLightDepth) return fail(RT_E_UNSUPPORTED, "lists nested more than 8 levels inside `lights`");
         const size_t base = out.lights.size();
         for (uint32_t k = 0; k < count; k++) {
             LightRec l;
-            if (!light_of(nodes[k], false, &l)) return false;
+            if (!light_of(nodes[k], &l)) return false;
             out.lights.push_back(l);
         }
         for (uint32_t k = 0; k < count; k++) {
@@ -713,11 +802,7 @@ struct Compiler {
             if (out.lights.size() >= (1u << kLightListShift) || n.n_children >= (1u << 11)) return fail(RT_E_UNSUPPORTED, "light list too large");
             out.lights[base + k].index = int32_t(out.lights.size() | (size_t(n.n_children) << kLightListShift));
             out.needs_tex_interpreter = true;  // the full-feature kernel variants evaluate nested light lists
-            for (uint32_t j = 0; j < n.n_children; j++) {
-                LightRec l;
-                if (!light_of(d.child_indices[n.first_child + j], true, &l)) return false;
-                out.lights.push_back(l);
-            }
+            if (!compile_light_entries(d.child_indices + n.first_child, n.n_children, depth + 1)) return false;
         }
         return true;
     }
@@ -729,12 +814,12 @@ struct Compiler {
             out.lights_is_list = 1;
             if (uint64_t(n.first_child) + n.n_children > d.n_child_indices) return fail(RT_E_INVALID, "child range out of bounds");
             out.n_top_lights = int32_t(n.n_children);
-            return compile_light_entries(d.child_indices + n.first_child, n.n_children);
+            return compile_light_entries(d.child_indices + n.first_child, n.n_children, 0);
         }
         out.lights_is_list = 0;
         out.n_top_lights = 1;
         uint32_t root = d.lights_root;
-        return compile_light_entries(&root, 1);
+        return compile_light_entries(&root, 1, 0);
     }
 
     // ---- CompiledScene::zero_weight_stop ----

@@ -45,6 +45,12 @@ struct CompiledScene {
     // otherwise they trace them to the end like the reference.
     bool zero_weight_stop = false;
     uint32_t n_rebuilt_groups = 0, n_rebuilt_prims = 0;  // object-BVH / list subtrees re-built as SAH trees (rt_compile.cpp)
+    // the same groups as 4-wide BVHs for k_wf_prims<GROUPS> (OP_GROUP, rt_scene.h)
+    std::vector<GroupRec<double>> groups;
+    std::vector<BuildNode4> group_nodes4;   // absolute child references; leaf codes index group_prims
+    std::vector<GroupPrimRef> group_prims;
+    std::vector<int32_t> group_guards;
+    uint32_t max_group_stack = 0;
 };
 
 struct CompileOptions {

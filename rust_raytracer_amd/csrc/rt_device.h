@@ -371,6 +371,70 @@ template <typename R> RT_DEV Ray<R> ray_in_chain_uniform(const SceneView<R>& sc,
     return make_ray(o, d);
 }
 
+// Volume::test (volume.rs:33-71) inside the scene program:  VOL_BEGIN <boundary ops> VOL_MID <boundary ops> VOL_END.
+// While a volume searches its boundary the caller's search state (closest hit so far, lower end of its interval) waits in a
+// frame; a volume INSIDE a boundary (its test runs once in each of the outer volume's two searches, draws included, in program
+// order) takes the next frame: kMaxVolDepth levels, kept in registers (every index below is a compile-time constant).
+template <typename R>
+struct VolFrames {  // two levels, spelled out member by member: arrays indexed by `depth` end up in scratch memory
+    Best<R> saved0, saved1;
+    R t_lo0, t_lo1;
+    R enter0, enter1;  // t of the boundary's entry hit (volume.rs:34)
+    int depth = 0;
+};
+static_assert(kMaxVolDepth == 2, "VolFrames spells out two levels");
+// volume.rs:34: boundary.test(ray, Interval::UNIVERSE)
+template <typename R> RT_DEV void vol_begin(VolFrames<R>& f, Best<R>& best, R& t_lo) {
+    if (f.depth == 0) { f.saved0 = best; f.t_lo0 = t_lo; }
+    else { f.saved1 = best; f.t_lo1 = t_lo; }
+    f.depth++;
+    best.t = Lim<R>::inf();
+    best.pc = -1;
+    t_lo = -Lim<R>::inf();
+}
+// volume.rs:35-37: no entry hit -> the volume is missed (returns true: jump to Op::skip); else second search over (t_enter + 0.0001, inf)
+template <typename R> RT_DEV bool vol_mid(VolFrames<R>& f, Best<R>& best, R& t_lo) {
+    if (best.pc < 0) {
+        f.depth--;
+        if (f.depth == 0) { best = f.saved0; t_lo = f.t_lo0; }
+        else { best = f.saved1; t_lo = f.t_lo1; }
+        return true;
+    }
+    if (f.depth == 1) f.enter0 = best.t;
+    else f.enter1 = best.t;
+    t_lo = best.t + R(0.0001);
+    best.t = Lim<R>::inf();
+    best.pc = -1;
+    return false;
+}
+// volume.rs:38-68: clamp to the caller's interval, draw the free-flight distance; a scattering event becomes the closest hit
+template <typename R> RT_DEV void vol_end(const SceneView<R>& sc, VolFrames<R>& f, Best<R>& best, R& t_lo, const Ray<R>& cur, const Op& op, int32_t pc, Rng& rng) {
+    const bool has_exit = best.pc >= 0;
+    const R t_exit = best.t;
+    R vol_enter;
+    f.depth--;
+    if (f.depth == 0) { best = f.saved0; t_lo = f.t_lo0; vol_enter = f.enter0; }
+    else { best = f.saved1; t_lo = f.t_lo1; vol_enter = f.enter1; }
+    if (has_exit) {
+        R t_min = fmax(vol_enter, t_lo);
+        R t_max = fmin(t_exit, best.t);
+        if (!(t_min >= t_max)) {
+            t_min = fmax(t_min, R(0));
+            R ray_len = length(cur.d);
+            R dist_inside = (t_max - t_min) * ray_len;
+            R uu = rng_uniform<R>(rng);
+            R hit_dist = sc.volumes[op.arg].neg_inv_density * (uu == R(0) ? -Lim<R>::inf() : log_r(uu));
+            if (!(hit_dist > dist_inside)) {
+                best.t = t_min + hit_dist / ray_len;
+                best.pc = pc;
+                best.tri = -1;
+                best.u = R(0);
+                best.v = R(0);
+            }
+        }
+    }
+}
+
 // world.test(ray, Interval(t_lo, inf)) — closest hit over the whole scene program.
 // Reproduces ObjectList::test (list.rs:58-74), BoundingVolumeHierarchyNode::test
 // (bvh.rs:84-101) and Transform::test (transform.rs:122-139): depth-first, fixed order,
@@ -388,60 +452,25 @@ RT_DEV void world_test(const SceneView<R>& sc, const Ray<R>& wray, const R t_lo_
     Ray<R> cur = wray;
     int32_t pc = 0;
     R t_lo = t_lo_outer;   // lower end of the current search interval (changes only inside a volume's boundary tests)
-    Best<R> saved = best;  // the caller's search state while a volume tests its boundary
-    R vol_enter = R(0);
+    VolFrames<R> vol;      // the callers' search states while volumes test their boundaries
     if (STATS) cnt.rays++;
     for (;;) {
         const Op op = sc.ops[pc];
         if (op.type == OP_END) break;
         switch (op.type) {
-            case OP_VOL_BEGIN:  // boundary.test(ray, Interval::UNIVERSE) (volume.rs:34)
-                if constexpr (VOL) {
-                    saved = best;
-                    best.t = Lim<R>::inf();
-                    best.pc = -1;
-                    t_lo = -Lim<R>::inf();
-                }
+            case OP_VOL_BEGIN:
+                if constexpr (VOL) vol_begin(vol, best, t_lo);
                 break;
-            case OP_VOL_MID:  // boundary.test(ray, (t_enter + 0.0001, inf)) (volume.rs:35-37)
+            case OP_VOL_MID:
                 if constexpr (VOL) {
-                    if (best.pc < 0) {
-                        best = saved;
-                        t_lo = t_lo_outer;
+                    if (vol_mid(vol, best, t_lo)) {
                         pc = op.skip;
                         continue;
                     }
-                    vol_enter = best.t;
-                    t_lo = vol_enter + R(0.0001);
-                    best.t = Lim<R>::inf();
-                    best.pc = -1;
                 }
                 break;
-            case OP_VOL_END:  // volume.rs:38-68
-                if constexpr (VOL) {
-                    const bool has_exit = best.pc >= 0;
-                    const R t_exit = best.t;
-                    best = saved;
-                    t_lo = t_lo_outer;
-                    if (has_exit) {
-                        R t_min = fmax(vol_enter, t_lo_outer);
-                        R t_max = fmin(t_exit, best.t);
-                        if (!(t_min >= t_max)) {
-                            t_min = fmax(t_min, R(0));
-                            R ray_len = length(cur.d);
-                            R dist_inside = (t_max - t_min) * ray_len;
-                            R uu = rng_uniform<R>(*rng);
-                            R hit_dist = sc.volumes[op.arg].neg_inv_density * (uu == R(0) ? -Lim<R>::inf() : log_r(uu));
-                            if (!(hit_dist > dist_inside)) {
-                                best.t = t_min + hit_dist / ray_len;
-                                best.pc = pc;
-                                best.tri = -1;
-                                best.u = R(0);
-                                best.v = R(0);
-                            }
-                        }
-                    }
-                }
+            case OP_VOL_END:
+                if constexpr (VOL) vol_end(sc, vol, best, t_lo, cur, op, pc, *rng);
                 break;
             case OP_BOUNDS:
                 if (!test_bounding_box(sc.bounds[op.arg], cur, t_lo, best.t)) {
@@ -624,11 +653,15 @@ template <typename R> RT_DEV V3<R> eval_texture_simple(const SceneView<R>& sc, i
     }
 }
 
-// Runs a postfix texture program (rt_scene.h) on a 4-deep value stack kept in registers: pushes and pops are
-// register moves, there is no indexed array.  Floats travel in .x.
+// Runs a postfix texture program (rt_scene.h).  The top four values of the stack live in registers (pushes and pops are
+// register moves, no indexed array): enough for every texture the reference's scenes build.  Deeper expressions - the
+// reference's recursion (interpolate.rs:29) has no limit - spill the values below the top four into a private array
+// (scratch memory; kTexStackMax live values in all), touched only by programs that need it.  Floats travel in .x.
 template <typename R> RT_DEV V3<R> eval_texture(const SceneView<R>& sc, int32_t prog, R u, R v, V3<R> p) {
     const int32_t first = prog & ((1 << kTexProgShift) - 1), count = prog >> kTexProgShift;
     V3<R> s0 = mk<R>(0, 0, 0), s1 = s0, s2 = s0, s3 = s0;  // s0 = top
+    V3<R> deep[kTexStackMax - kTexStackDepth];                // deep[k] = the value k + 5 from the top... kept in push order
+    int live = 0;                                              // values on the stack
 #pragma clang loop unroll(disable)
     for (int32_t k = 0; k < count; k++) {
         const TextureRec<R>& tx = sc.textures[first + k];
@@ -639,6 +672,8 @@ template <typename R> RT_DEV V3<R> eval_texture(const SceneView<R>& sc, int32_t 
                 s0 = ((iu + iv) % 2u) == 0u ? s1 : s0;
                 s1 = s2;
                 s2 = s3;
+                if (live > 4) s3 = deep[live - 5];
+                live -= 1;
                 break;
             }
             case RT_TEX_CHECKER_SOLID: {  // checkerboard.rs:74-85
@@ -649,6 +684,8 @@ template <typename R> RT_DEV V3<R> eval_texture(const SceneView<R>& sc, int32_t 
                 s0 = (sum % 2) == 0 ? s1 : s0;
                 s1 = s2;
                 s2 = s3;
+                if (live > 4) s3 = deep[live - 5];
+                live -= 1;
                 break;
             }
             case RT_TEX_LERP: {  // interpolate.rs:29-39; s2 = start, s1 = end, s0 = t
@@ -659,6 +696,9 @@ template <typename R> RT_DEV V3<R> eval_texture(const SceneView<R>& sc, int32_t 
                 else r = s2 * (R(1) - t) + s1 * t;
                 s0 = r;
                 s1 = s3;
+                if (live > 4) s2 = deep[live - 5];
+                if (live > 5) s3 = deep[live - 6];
+                live -= 2;
                 break;
             }
             case RT_TEX_CHANNEL:  // channel.rs:22-25 (index 3 = the colour's w, always 0)
@@ -670,10 +710,12 @@ template <typename R> RT_DEV V3<R> eval_texture(const SceneView<R>& sc, int32_t 
                 else if (tx.type == RT_TEX_IMAGE) val = image_sample(sc, tx, u, v);
                 else if (tx.type == RT_TEX_NOISE_SOLID) val = mk<R>(noise_solid_sample(sc, tx, p), R(0), R(0));
                 else val = ld3(tx.v);  // constant.rs:30 (a float constant keeps its value in v[0])
+                if (live >= 4) deep[live - 4] = s3;
                 s3 = s2;
                 s2 = s1;
                 s1 = s0;
                 s0 = val;
+                live += 1;
                 break;
             }
         }
@@ -872,25 +914,45 @@ template <typename R, bool STATS> RT_DEV R light_pdf_value(const SceneView<R>& s
         default: return R(0);                             // Transform / mesh / bvh / volume
     }
 }
-// A member of `lights` that is itself an ObjectList (FULL kernel variants only): list.rs:80-89 once more
-template <typename R, bool STATS> RT_DEV R light_list_pdf_value(const SceneView<R>& sc, const LightRec& l, V3<R> origin, V3<R> dir, LaneCounters& cnt) {
-    const int32_t first = l.index & ((1 << kLightListShift) - 1), count = l.index >> kLightListShift;
-    R weight = R(1) / R(count);
-    R sum = R(0);
-    for (int32_t j = 0; j < count; j++) sum += weight * light_pdf_value<R, STATS>(sc, sc.lights[first + j], origin, dir, cnt);
-    return sum;
-}
-// lights.pdf_value(origin, dir): ObjectList (list.rs:80-89) or the single object
+// lights.pdf_value(origin, dir): ObjectList (list.rs:80-89: weight = 1 / n, sum of weight * member.pdf_value in member order,
+// starting from 0) or the single object.  FULL kernel variants: members may be ObjectLists themselves, to any depth the scene
+// compiler accepts (kMaxLightDepth); the reference's recursion becomes an explicit stack of (list, next member, partial sum),
+// so that every partial sum is formed in the reference's order.
 template <typename R, bool STATS, bool FULL> RT_DEV R lights_pdf_value(const SceneView<R>& sc, V3<R> origin, V3<R> dir, LaneCounters& cnt) {
     if (!sc.lights_is_list) return light_pdf_value<R, STATS>(sc, sc.lights[0], origin, dir, cnt);
-    R weight = R(1) / R(sc.n_lights);
-    R sum = R(0);
-    for (int32_t i = 0; i < sc.n_lights; i++) {
-        const LightRec l = sc.lights[i];
-        if (FULL && l.kind == LIGHT_LIST) sum += weight * light_list_pdf_value<R, STATS>(sc, l, origin, dir, cnt);
-        else sum += weight * light_pdf_value<R, STATS>(sc, l, origin, dir, cnt);
+    if constexpr (!FULL) {
+        R weight = R(1) / R(sc.n_lights);
+        R sum = R(0);
+        for (int32_t i = 0; i < sc.n_lights; i++) sum += weight * light_pdf_value<R, STATS>(sc, sc.lights[i], origin, dir, cnt);
+        return sum;
+    } else {
+        int32_t first[kMaxLightDepth], count[kMaxLightDepth], next[kMaxLightDepth];
+        R sum[kMaxLightDepth], weight[kMaxLightDepth];
+        int depth = 0;
+        first[0] = 0; count[0] = sc.n_lights; next[0] = 0; sum[0] = R(0); weight[0] = R(1) / R(sc.n_lights);
+        for (;;) {
+            if (next[depth] == count[depth]) {  // this list is summed up: hand the value to its parent
+                if (depth == 0) return sum[0];
+                const R value = sum[depth];
+                depth--;
+                sum[depth] += weight[depth] * value;
+                next[depth]++;
+                continue;
+            }
+            const LightRec l = sc.lights[first[depth] + next[depth]];
+            if (l.kind == LIGHT_LIST && depth + 1 < kMaxLightDepth) {
+                depth++;
+                first[depth] = l.index & ((1 << kLightListShift) - 1);
+                count[depth] = l.index >> kLightListShift;
+                next[depth] = 0;
+                sum[depth] = R(0);
+                weight[depth] = R(1) / R(count[depth]);
+                continue;
+            }
+            sum[depth] += weight[depth] * light_pdf_value<R, STATS>(sc, l, origin, dir, cnt);
+            next[depth]++;
+        }
     }
-    return sum;
 }
 template <typename R> RT_DEV V3<R> light_random(const SceneView<R>& sc, const LightRec& l, V3<R> origin, Rng& rng) {
     switch (l.kind) {
@@ -928,10 +990,12 @@ template <typename R, bool FULL> RT_DEV V3<R> lights_random(const SceneView<R>& 
     if (sc.n_lights == 0) return mk<R>(1, 0, 0);  // list.rs:93-95
     uint32_t idx = rng.below(uint32_t(sc.n_lights));
     LightRec l = sc.lights[idx];
-    if (FULL && l.kind == LIGHT_LIST) {  // the member is an ObjectList: list.rs:91-100 once more
-        const int32_t first = l.index & ((1 << kLightListShift) - 1), count = l.index >> kLightListShift;
-        if (count == 0) return mk<R>(1, 0, 0);
-        l = sc.lights[first + int32_t(rng.below(uint32_t(count)))];
+    if constexpr (FULL) {
+        while (l.kind == LIGHT_LIST) {  // the member is an ObjectList: list.rs:91-100 again, as deep as the lists nest
+            const int32_t first = l.index & ((1 << kLightListShift) - 1), count = l.index >> kLightListShift;
+            if (count == 0) return mk<R>(1, 0, 0);
+            l = sc.lights[first + int32_t(rng.below(uint32_t(count)))];
+        }
     }
     return light_random(sc, l, origin, rng);
 }

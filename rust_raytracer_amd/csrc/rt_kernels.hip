@@ -308,6 +308,7 @@ struct DeviceScene {
         // power of two (cell * iv exact), so against the f32-node test (fma(plane, iv, -o * iv)) there is one more rounding,
         // of a value bounded by 2 S |iv|; with it the error is < 2.5 x 2^-23 S |iv| per plane, inside the padding.
         std::vector<BvhNode4q> nodes4q(cs.nodes4.size());
+        std::vector<BvhNode4q> group_nodes;
         {
             auto pad_of = [&]() {
                 std::vector<std::pair<uint32_t, double>> pads;
@@ -376,6 +377,21 @@ struct DeviceScene {
                 if (!quantise(4, sn.lo, sn.hi, sn.child, pads4.empty() ? 0.0 : pads4[pi].second, qn.org, qn.cell, qn.qlo, qn.qhi, qn.child))
                     return set_err(RT_E_UNSUPPORTED, "BVH node does not fit the 8-bit grid");
             }
+            // the primitive groups' BVHs: same node format, same padding rule (2^-19 x the largest |coordinate| of the group's box)
+            group_nodes.resize(cs.group_nodes4.size());
+            for (size_t g = 0; g < cs.groups.size(); g++) {
+                const GroupRec<double>& gr = cs.groups[g];
+                double S = 0.0;
+                for (int a = 0; a < 3; a++) S = std::fmax(S, std::fmax(std::fabs(gr.lo[a]), std::fabs(gr.hi[a])));
+                if (!std::isfinite(S)) return set_err(RT_E_UNSUPPORTED, "primitive group with an unbounded box");
+                const size_t end = g + 1 < cs.groups.size() ? cs.groups[g + 1].root : cs.group_nodes4.size();
+                for (size_t i = gr.root; i < end; i++) {
+                    const BuildNode4& sn = cs.group_nodes4[i];
+                    BvhNode4q& qn = group_nodes[i];
+                    if (!quantise(4, sn.lo, sn.hi, sn.child, S * (1.0 / 524288.0), qn.org, qn.cell, qn.qlo, qn.qhi, qn.child))
+                        return set_err(RT_E_UNSUPPORTED, "group BVH node does not fit the 8-bit grid");
+                }
+            }
         }
         std::vector<Bounds<R>> mesh_bounds(cs.mesh_bounds.size());
         for (size_t i = 0; i < mesh_bounds.size(); i++)
@@ -442,10 +458,23 @@ struct DeviceScene {
             r.pc = cs.mesh_ops[m];
             r.chain = op.chain;
             r.node4_base = mi.node4_base;
-            r.flags = mi.flags;
+            const int32_t cb = cs.chain_offsets[size_t(op.chain)], ce = cs.chain_offsets[size_t(op.chain) + 1];
+            r.flags = (mi.flags & 0xFFFFu) | (uint32_t(std::min(ce - cb, 0xFFFF)) << 16);
             for (int a = 0; a < 3; a++) { r.lo[a] = mesh_bounds[size_t(op.arg)].lo[a]; r.hi[a] = mesh_bounds[size_t(op.arg)].hi[a]; }
+            for (int k = 0; k < 12; k++) r.inv[k] = ce - cb == 1 ? xforms[size_t(cs.chain_items[size_t(cb)])].inv[k] : R(0);
         }
         if ((st = buf.upload(mesh_op_recs, &view.mesh_op_recs)) != RT_OK) return st;
+        std::vector<GroupRec<R>> groups(cs.groups.size());
+        for (size_t g = 0; g < groups.size(); g++) {
+            groups[g].root = cs.groups[g].root;
+            for (int a = 0; a < 3; a++) { groups[g].lo[a] = round_down<R>(cs.groups[g].lo[a]); groups[g].hi[a] = round_up<R>(cs.groups[g].hi[a]); }
+        }
+        if ((st = buf.upload(groups, &view.groups)) != RT_OK) return st;
+        if ((st = buf.upload(group_nodes, &view.group_nodes)) != RT_OK) return st;
+        if ((st = buf.upload(cs.group_prims, &view.group_prims)) != RT_OK) return st;
+        if ((st = buf.upload(cs.group_guards, &view.group_guards)) != RT_OK) return st;
+        view.n_group_nodes = int32_t(group_nodes.size());
+        view.group_stack_levels = int32_t(cs.max_group_stack);
         if ((st = buf.upload(tris, &view.tris)) != RT_OK) return st;
         if ((st = buf.upload(attrs, &view.attrs)) != RT_OK) return st;
         if ((st = buf.upload(cs.materials, &view.materials)) != RT_OK) return st;
@@ -767,6 +796,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     const bool use_split = env_u32("RT_WF_SPLIT", 1) != 0 && vol_split_ok && n_mesh_ops < 32767;  // k_wf_mesh packs the mesh-op index in 15 bits
     const bool prims_only = use_split && n_mesh_ops == 0;
     const bool split = use_split && n_mesh_ops > 0;
+    const bool multi_mesh = n_mesh_ops > 1 || env_u32("RT_WF_MESH_MULTI", 0) != 0;  // the general form of k_wf_mesh (env: A/B on single-mesh scenes, tests)
     // k_wf_mesh keeps (child, entry distance) pairs: a shallow LDS part (occupancy) + a global spill part
     // BVH node format of k_wf_mesh: 1 = 4-wide quantised (BvhNode4q, 64 B, default), 0 = 4-wide f32 (BvhNode4f, 128 B; A/B control).
     // An 8-wide quantised node (a third fewer visits) was slower: profiles/r02/ab/node_width_and_size.txt.
@@ -775,7 +805,8 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     const int lds_levels = std::min<int>(mesh_levels, int(env_u32("RT_WF_LDS_LEVELS", 12)));
     const size_t lds_mesh = size_t(lds_levels) * 256 * sizeof(uint2) + 4 * kMeshWaveLds<R>;
     if (split) {
-#define RT_MESH_OCC(ST, ND) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_mesh<R, ST, ND>, 256, lds_mesh))
+#define RT_MESH_OCC(ST, ND) do { if (multi_mesh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_mesh<R, ST, ND, true>, 256, lds_mesh)); \
+                                 else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_mesh<R, ST, ND, false>, 256, lds_mesh)); } while (0)
         if (stats) { if (node_kind == 1) RT_MESH_OCC(true, 1); else RT_MESH_OCC(true, 0); }
         else { if (node_kind == 1) RT_MESH_OCC(false, 1); else RT_MESH_OCC(false, 0); }
 #undef RT_MESH_OCC
@@ -813,7 +844,16 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
         }
         return (best + 15u) & ~15u;
     };
-    const uint32_t staged_prims = staged_prefix(ds.view.lay), staged_shade = staged_prefix(ds.view.lay_shade);
+    // re-built primitive groups as 4-wide BVHs inside k_wf_prims (OP_GROUP): nodes + a per-lane stack in LDS; scenes whose
+    // groups need more than that LDS (> 24 KB of nodes, > 16 stack levels) keep the op form.  RT_WF_GROUPS=0: A/B, tests.
+    const uint32_t group_levels = uint32_t(ds.view.group_stack_levels);
+    const size_t group_node_bytes = size_t(ds.view.n_group_nodes) * sizeof(BvhNode4q);
+    const bool groups = (split || prims_only) && !vol && ds.view.n_group_nodes > 0 && group_levels <= 16 && group_node_bytes <= 24u * 1024u &&
+                        env_u32("RT_WF_GROUPS", 1) != 0;
+    const size_t lds_groups = groups ? size_t(group_levels) * 256 * 8 + group_node_bytes : 0;
+    uint32_t staged_prims = staged_prefix(ds.view.lay);
+    const uint32_t staged_shade = staged_prefix(ds.view.lay_shade);
+    if (groups && lds_groups + staged_prims > 44u * 1024u) staged_prims = 0;  // three workgroups per CU with the group data: tables from global memory
     const int lds_prims = staged_prims == 0 ? 0 : (staged_prims == ds.view.lay.total_bytes ? 1 : 2);          // kernel variant: none / all / prefix
     // k_wf_shade: all or nothing (a staged prefix read through flat instructions was 3 % slower than global memory on the default scene)
     const int lds_shade = (staged_shade != 0 && staged_shade == ds.view.lay_shade.total_bytes) ? 1 : (env_u32("RT_LDS_SHADE_PREFIX", 0) && staged_shade ? 2 : 0);
@@ -855,11 +895,14 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
         hipLaunchKernelGGL((k_wf_generate<R>), dim3((first + 255) / 256), dim3(256), 0, stream, pool, first, grp, cv, pv, w.queue[0]);
         int qi = 0;
         uint32_t upper = first;  // upper bound of the queue length (never grows: slots are reused in place)
-#define RT_LAUNCH_PRIMS(ST, L, VL) hipLaunchKernelGGL((k_wf_prims<R, ST, L, VL>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), (L ? size_t(staged_prims) : size_t(0)) + (WF_CHUNK + 4) * 4, stream, ds.view, pool, w.queue[qi], w.mesh_queue, w.d_ctr, s->d_counters, staged_prims)
-#define RT_LAUNCH_PRIMS_ANY() do { if (vol) { if (stats) RT_LAUNCH_PRIMS(true, 0, true); else RT_LAUNCH_PRIMS(false, 0, true); } \
-                                   else if (stats) { if (lds_prims == 1) RT_LAUNCH_PRIMS(true, 1, false); else if (lds_prims == 2) RT_LAUNCH_PRIMS(true, 2, false); else RT_LAUNCH_PRIMS(true, 0, false); } \
-                                   else { if (lds_prims == 1) RT_LAUNCH_PRIMS(false, 1, false); else if (lds_prims == 2) RT_LAUNCH_PRIMS(false, 2, false); else RT_LAUNCH_PRIMS(false, 0, false); } } while (0)
-#define RT_LAUNCH_MESH_V(ST, ND, QUEUE, NPTR, CPTR) hipLaunchKernelGGL((k_wf_mesh<R, ST, ND>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, QUEUE, w.d_ctr, s->d_counters, refill_min, inner_min, static_cast<uint2*>(w.mesh_spill), lds_levels, NPTR, CPTR)
+#define RT_LAUNCH_PRIMS(ST, L, VL, GR) hipLaunchKernelGGL((k_wf_prims<R, ST, L, VL, GR>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), (L ? size_t(staged_prims) : size_t(0)) + (GR ? lds_groups : size_t(0)) + (WF_CHUNK + 4) * 4, stream, ds.view, pool, w.queue[qi], w.mesh_queue, w.d_ctr, s->d_counters, staged_prims, group_levels)
+#define RT_LAUNCH_PRIMS_ANY() do { if (vol) { if (stats) RT_LAUNCH_PRIMS(true, 0, true, false); else RT_LAUNCH_PRIMS(false, 0, true, false); } \
+                                   else if (groups) { if (stats) { if (lds_prims == 2) RT_LAUNCH_PRIMS(true, 2, false, true); else if (lds_prims == 1) RT_LAUNCH_PRIMS(true, 1, false, true); else RT_LAUNCH_PRIMS(true, 0, false, true); } \
+                                                      else { if (lds_prims == 2) RT_LAUNCH_PRIMS(false, 2, false, true); else if (lds_prims == 1) RT_LAUNCH_PRIMS(false, 1, false, true); else RT_LAUNCH_PRIMS(false, 0, false, true); } } \
+                                   else if (stats) { if (lds_prims == 1) RT_LAUNCH_PRIMS(true, 1, false, false); else if (lds_prims == 2) RT_LAUNCH_PRIMS(true, 2, false, false); else RT_LAUNCH_PRIMS(true, 0, false, false); } \
+                                   else { if (lds_prims == 1) RT_LAUNCH_PRIMS(false, 1, false, false); else if (lds_prims == 2) RT_LAUNCH_PRIMS(false, 2, false, false); else RT_LAUNCH_PRIMS(false, 0, false, false); } } while (0)
+#define RT_LAUNCH_MESH_M(ST, ND, MU, QUEUE, NPTR, CPTR) hipLaunchKernelGGL((k_wf_mesh<R, ST, ND, MU>), dim3(isect_blocks), dim3(256), lds_mesh, stream, ds.view, pool, QUEUE, w.d_ctr, s->d_counters, refill_min, inner_min, static_cast<uint2*>(w.mesh_spill), lds_levels, NPTR, CPTR)
+#define RT_LAUNCH_MESH_V(ST, ND, QUEUE, NPTR, CPTR) do { if (multi_mesh) RT_LAUNCH_MESH_M(ST, ND, true, QUEUE, NPTR, CPTR); else RT_LAUNCH_MESH_M(ST, ND, false, QUEUE, NPTR, CPTR); } while (0)
 #define RT_LAUNCH_MESH(QUEUE, NPTR, CPTR)                                                                                                         \
     do {                                                                                                                                          \
         if (stats) { if (node_kind == 1) RT_LAUNCH_MESH_V(true, 1, QUEUE, NPTR, CPTR); else RT_LAUNCH_MESH_V(true, 0, QUEUE, NPTR, CPTR); } \
@@ -941,6 +984,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
 #undef RT_LAUNCH_PRIMS
 #undef RT_LAUNCH_MESH
 #undef RT_LAUNCH_MESH_V
+#undef RT_LAUNCH_MESH_M
         hipLaunchKernelGGL(k_wf_resolve, dim3(uint32_t((npix + 255) / 256)), dim3(256), 0, stream, w.sample_L, w.acc, npix, strata, nrep,
                            pv.spp, int(t0 == 0), d_out, int(t0 + nrep >= T));
     }

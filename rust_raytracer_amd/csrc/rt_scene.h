@@ -28,6 +28,13 @@ enum OpType : int32_t {
     OP_VOL_BEGIN = 9,   // save the search state; boundary test over Interval::UNIVERSE
     OP_VOL_MID = 10,    // no entry hit: restore, jump to `skip`; else second test over (t_enter + 0.0001, inf)
     OP_VOL_END = 11,    // arg = volume idx: clamp to the caller's interval, draw the scattering distance
+    // A re-built primitive group (rt_compile.cpp: a list / object-BVH subtree of spheres and quads) exists in TWO forms:
+    // as skip-pointer ops (OP_BOUNDS tree, the form every interpreter understands) and as a 4-wide quantised BVH over the
+    // same primitives (SceneView::group_*).  OP_GROUP stands in front of the op form: arg = group idx, skip = pc behind the
+    // subtree.  k_wf_prims<GROUPS> searches the BVH (nearest child first, per-lane stack in LDS) and jumps to `skip`; the
+    // other interpreters treat the op as a no-op and walk the ops behind it.  Same closest hit either way: both forms test
+    // the same primitives with the same exact arithmetic, boxes only cull, ties go by rank (hit_takes_over).
+    OP_GROUP = 12,
 };
 
 struct Op {
@@ -79,6 +86,19 @@ struct VolumeRec {  // volume.rs:15-19
     int32_t _pad;
 };
 
+template <typename R>
+struct GroupRec {
+    uint32_t root;        // root node in SceneView::group_nodes
+    uint32_t _pad[3];
+    R lo[3], hi[3];       // box of the group's primitives (exact, rounded outward in f32 builds): the culling ray starts on it
+};
+struct GroupPrimRef {
+    int32_t pc;           // the primitive's op inside the group's op form (type, arg, rank, chain): also the `pc` of its hits
+    int32_t guard_first;  // guard boxes (reference ancestor boxes that do not contain the primitive, SURVEY B-8): indices
+    int32_t guard_count;  // into SceneView::group_guards -> SceneView::bounds, tested with the reference's Williams test
+    int32_t _pad;
+};
+
 struct MeshInst {
     uint32_t node_base;  // first BVH node of this mesh in nodes[]
     uint32_t tri_base;   // first triangle record in tris[] / attrs[]
@@ -98,8 +118,10 @@ struct alignas(16) MeshOpRec {
     int32_t pc;           // the OP_MESH op
     int32_t chain;        // its transform chain (Op::chain)
     uint32_t node4_base;  // root of the mesh's 4-wide BVH
-    uint32_t flags;       // MeshInst::flags
+    uint32_t flags;       // MeshInst::flags | chain length << 16
     R lo[3], hi[3];       // SceneView::mesh_bounds of the instance
+    R inv[12];            // chain length 1 (a mesh inside one Transform, the usual case): that transform's inverse, so that
+                          // entering the mesh costs ONE scalar-load round trip instead of record -> chain -> item -> matrix
 };
 
 
@@ -169,7 +191,7 @@ struct MaterialParams {
 };
 
 // Texture expressions are compiled to POSTFIX programs (rt_compile.cpp): a material slot holds
-// (first op | op count << 20); operands are evaluated before their operator onto a 4-deep value stack:
+// (first op | op count << 20); operands are evaluated before their operator onto a value stack (top four in registers):
 //   CONST_COLOR / CONST_FLOAT / UV_DEBUG / IMAGE / NOISE_SOLID   push a value
 //   CHECKER / CHECKER_SOLID   [even][odd] -> the one the parity rule selects (checkerboard.rs:34-44, 74-85)
 //   LERP                      [start][end][t] -> interpolate.rs:29-39
@@ -186,16 +208,20 @@ struct TextureRec {  // texture/*.rs
     R v[3];          // CONST_*: value; NOISE_SOLID: scale vector
     R scale;         // CHECKER*
 };
-constexpr int kTexStackDepth = 4;
+constexpr int kMaxVolDepth = 2;     // a volume and a volume inside its boundary (VolFrames, rt_device.h: one register frame per level)
+constexpr int kTexStackDepth = 4;   // values of eval_texture's stack kept in registers
+constexpr int kTexStackMax = 16;    // live values a texture program may need (the rest spill to a private array)
 constexpr int32_t kTexProgShift = 20;  // program id = first op | (op count << 20)
 
 enum LightKind : int32_t { LIGHT_OTHER = 0, LIGHT_PLANE = 1, LIGHT_SPHERE = 2, LIGHT_SKY = 3, LIGHT_SUN = 4, LIGHT_LIST = 5 };
 struct LightRec {
     int32_t kind;
     int32_t index;  // into planes / spheres / suns; LIGHT_LIST (an ObjectList inside `lights`, e.g. an emissive box):
-                    // first member in lights[] | member count << 20 (members are stored behind the top-level entries)
+                    // first member in lights[] | member count << 20 (the members of a list are contiguous; members that are
+                    // lists themselves point further back: a tree, as deep as kMaxLightDepth)
 };
 constexpr int32_t kLightListShift = 20;
+constexpr int kMaxLightDepth = 8;  // nesting levels of ObjectLists inside `lights` (explicit evaluation stack in lights_pdf_value)
 
 // All the small tables (everything except BVH nodes, triangle records and attributes) are ALSO uploaded as contiguous
 // blobs, so that a workgroup can stage them in LDS with one cooperative copy and walk the scene program / materials /
@@ -232,6 +258,12 @@ struct SceneView {
     const int32_t* mesh_ops;       // pcs of the OP_MESH ops in program order: k_wf_prims defers them, k_wf_mesh serves them one after the other
     const MeshOpRec<R>* mesh_op_recs;  // the same ops as k_wf_mesh wants them
     int32_t n_mesh_ops;
+    const GroupRec<R>* groups;         // re-built primitive groups (OP_GROUP)
+    const BvhNode4q* group_nodes;      // their 4-wide quantised BVHs (absolute child references; leaves index group_prims)
+    const GroupPrimRef* group_prims;
+    const int32_t* group_guards;
+    int32_t n_group_nodes;
+    int32_t group_stack_levels;        // worst-case traversal stack of any group (0: no groups)
     const TriRec<R>* tris;
     const TriAttr<R>* attrs;
     const MaterialRec* materials;

@@ -185,7 +185,7 @@ RT_DEV bool wave_fetch(WaveRange& r, unsigned long long idle, uint32_t* cursor, 
 // VOL: the program contains volume ops (OP_VOL_*): the search then carries the path's RNG (Volume::test draws the
 // free-flight distance in the middle of it, volume.rs:47) and a second search state for the boundary tests.
 template <typename R, bool STATS, bool VOL>
-__global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<R> sc, WfPool<R> pool, const uint32_t* __restrict__ queue,
+__global__ void __launch_bounds__(256, VOL ? 2 : RT_ISECT_WAVES) k_wf_intersect(SceneView<R> sc, WfPool<R> pool, const uint32_t* __restrict__ queue,
                                                       WfCounters* __restrict__ ctr, DeviceCounters* counters, uint32_t refill_min) {
     extern __shared__ int lds_stack[];
     int* stack = lds_stack + threadIdx.x;
@@ -193,8 +193,7 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<
     const uint32_t n = ctr->n_in;
     const R t_lo_outer = R(0.001);
     R t_lo = t_lo_outer;     // changes only inside a volume's boundary searches
-    Best<R> saved{};         // VOL: the caller's search state during a boundary search
-    R vol_enter = R(0);
+    VolFrames<R> vol;        // VOL: the callers' search states during boundary searches
     Rng rng;
     rng.s = 0;
 
@@ -230,7 +229,7 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<
                 pc = 0;
                 has = true;
                 in_mesh = false;
-                if constexpr (VOL) { rng.s = at(pool.rng, slot); t_lo = t_lo_outer; }
+                if constexpr (VOL) { rng.s = at(pool.rng, slot); t_lo = t_lo_outer; vol.depth = 0; }
                 if (STATS) cnt.rays++;
             }
         }
@@ -267,53 +266,19 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<
                     break;
                 }
                 switch (op.type) {
-                    case OP_VOL_BEGIN:  // volume.rs:34: boundary.test(ray, Interval::UNIVERSE)
-                        if constexpr (VOL) {
-                            saved = best;
-                            best.t = Lim<R>::inf();
-                            best.pc = -1;
-                            t_lo = -Lim<R>::inf();
-                        }
+                    case OP_VOL_BEGIN:
+                        if constexpr (VOL) vol_begin(vol, best, t_lo);
                         break;
-                    case OP_VOL_MID:  // volume.rs:35-37: second search over (t_enter + 0.0001, inf)
+                    case OP_VOL_MID:
                         if constexpr (VOL) {
-                            if (best.pc < 0) {
-                                best = saved;
-                                t_lo = t_lo_outer;
+                            if (vol_mid(vol, best, t_lo)) {
                                 pc = op.skip;
                                 continue;
                             }
-                            vol_enter = best.t;
-                            t_lo = vol_enter + R(0.0001);
-                            best.t = Lim<R>::inf();
-                            best.pc = -1;
                         }
                         break;
-                    case OP_VOL_END:  // volume.rs:38-68
-                        if constexpr (VOL) {
-                            const bool has_exit = best.pc >= 0;
-                            const R t_exit = best.t;
-                            best = saved;
-                            t_lo = t_lo_outer;
-                            if (has_exit) {
-                                R t_min = fmax(vol_enter, t_lo_outer);
-                                R t_max = fmin(t_exit, best.t);
-                                if (!(t_min >= t_max)) {
-                                    t_min = fmax(t_min, R(0));
-                                    R ray_len = length(cur.d);
-                                    R dist_inside = (t_max - t_min) * ray_len;
-                                    R uu = rng_uniform<R>(rng);
-                                    R hit_dist = sc.volumes[op.arg].neg_inv_density * (uu == R(0) ? -Lim<R>::inf() : log_r(uu));
-                                    if (!(hit_dist > dist_inside)) {
-                                        best.t = t_min + hit_dist / ray_len;
-                                        best.pc = pc;
-                                        best.tri = -1;
-                                        best.u = R(0);
-                                        best.v = R(0);
-                                    }
-                                }
-                            }
-                        }
+                    case OP_VOL_END:
+                        if constexpr (VOL) vol_end(sc, vol, best, t_lo, cur, op, pc, rng);
                         break;
                     case OP_BOUNDS:
                         if (!test_bounding_box(sc.bounds[op.arg], cur, t_lo, best.t)) {
@@ -446,6 +411,129 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<
 // Closest-hit semantics are those of the in-order program: the nearest t wins and, at exactly equal
 // t, the op that comes first in the reference's visiting order (its tests use strict `t < closest`).
 // ---------------------------------------------------------------------------------------------
+// f32 value that is certainly >= x (x finite or +inf): round to nearest, then add a relative margin.
+RT_DEV float f32_at_least(double x) {
+    float f = float(x);
+    return f + fabsf(f) * 9.5367431640625e-7f + 1e-30f;  // 2^-20 relative
+}
+RT_DEV float f32_at_least(float x) { return x + fabsf(x) * 9.5367431640625e-7f + 1e-30f; }
+
+typedef __attribute__((address_space(3))) unsigned long long LdsU64;
+
+// ---------------------------------------------------------------------------------------------
+// Re-built primitive groups (OP_GROUP): closest hit of the ray with the group's spheres / quads through the group's 4-wide
+// quantised BVH - the node format, the conservative f32 slab test on a ray clipped to the group's box, the nearest-first
+// order and the (child, entry distance) stack entries culled on pop are those of k_wf_mesh; the leaves hold primitives
+// instead of triangles and are tested by the lane itself with the exact tests of the scene program (sphere.rs:40-62,
+// plane.rs:66-89, ties by rank).  The default scene's 455-sphere field costs a ray ~5 node steps and ~3 sphere tests this
+// way, against ~50 serial ops of the skip-pointer form (each op a dependent fetch: 101 of the scene's 177 ms per step).
+// ---------------------------------------------------------------------------------------------
+struct GroupCtx {
+    const BvhNode4q* nodes;  // SceneView::group_nodes, or their copy in LDS
+    LdsU64* stack;           // this lane's column of the workgroup's LDS stack: entry k at stack[k * 256]
+};
+
+template <typename R, bool STATS>
+RT_DEV void group_search(const SceneView<R>& sc, const GroupCtx& gc, const GroupRec<R>& g, const Ray<R>& cur, R t_lo, Best<R>& best, LaneCounters& cnt) {
+    const R big = sizeof(R) == 8 ? R(1e150) : R(1e18);
+    const V3<R> inv = {fabs(cur.inv.x) > big ? copysign(big, cur.inv.x) : cur.inv.x,
+                       fabs(cur.inv.y) > big ? copysign(big, cur.inv.y) : cur.inv.y,
+                       fabs(cur.inv.z) > big ? copysign(big, cur.inv.z) : cur.inv.z};
+    // entry into the group's box (>= 0) and exit; the culling origin is o + d * t_shift, so that its f32 image is no larger than the box
+    const R e0x = (g.lo[0] - cur.o.x) * inv.x, e1x = (g.hi[0] - cur.o.x) * inv.x;
+    const R e0y = (g.lo[1] - cur.o.y) * inv.y, e1y = (g.hi[1] - cur.o.y) * inv.y;
+    const R e0z = (g.lo[2] - cur.o.z) * inv.z, e1z = (g.hi[2] - cur.o.z) * inv.z;
+    R t_shift = fmax(fmax(fmin(e0x, e1x), fmin(e0y, e1y)), fmax(fmin(e0z, e1z), R(0)));
+    const R t_exit = fmin(fmin(fmax(e0x, e1x), fmax(e0y, e1y)), fmax(e0z, e1z));
+    const R eps = Lim<R>::eps() * R(16);  // a miss only if it is one with a few ulps of slack (a NaN compares false: the group is searched)
+    if ((t_shift - fabs(t_shift) * eps > t_exit + fabs(t_exit) * eps) || (t_shift - fabs(t_shift) * eps > best.t)) return;
+    if (!(t_shift < Lim<R>::inf())) t_shift = R(0);
+    const V3<R> oc = cur.o + cur.d * t_shift;
+    const float big32 = 1e18f;
+    float ivx = 1.0f / float(cur.d.x), ivy = 1.0f / float(cur.d.y), ivz = 1.0f / float(cur.d.z);
+    ivx = fabsf(ivx) > big32 ? copysignf(big32, ivx) : ivx;
+    ivy = fabsf(ivy) > big32 ? copysignf(big32, ivy) : ivy;
+    ivz = fabsf(ivz) > big32 ? copysignf(big32, ivz) : ivz;
+    const float oix = float(oc.x) * ivx, oiy = float(oc.y) * ivy, oiz = float(oc.z) * ivz;
+    const bool negx = ivx < 0.0f, negy = ivy < 0.0f, negz = ivz < 0.0f;
+    float tmax32 = f32_at_least(best.t - t_shift);
+    int32_t node = int32_t(g.root);
+    int sp = 0;
+    for (;;) {
+        bool pop = false;
+        if (node >= 0) {
+            if (STATS) cnt.node_visits++;
+            const float miss = __builtin_huge_valf();
+            const uint4* nd = reinterpret_cast<const uint4*>(gc.nodes + node);
+            const uint4 h0 = nd[0], h1 = nd[1], h2 = nd[2];
+            const int4 cc = *reinterpret_cast<const int4*>(nd + 3);
+            float nr[4];
+            int32_t ch[4] = {cc.x, cc.y, cc.z, cc.w};
+            const float ax = __uint_as_float(h0.w) * ivx, ay = __uint_as_float(h1.x) * ivy, az = __uint_as_float(h1.y) * ivz;
+            const float bx = fmaf(__uint_as_float(h0.x), ivx, -oix), by = fmaf(__uint_as_float(h0.y), ivy, -oiy), bz = fmaf(__uint_as_float(h0.z), ivz, -oiz);
+            const uint32_t qnx = negx ? h2.y : h1.z, qfx = negx ? h1.z : h2.y;
+            const uint32_t qny = negy ? h2.z : h1.w, qfy = negy ? h1.w : h2.z;
+            const uint32_t qnz = negz ? h2.w : h2.x, qfz = negz ? h2.x : h2.w;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float nxk = float((qnx >> (8 * k)) & 0xFFu), nyk = float((qny >> (8 * k)) & 0xFFu), nzk = float((qnz >> (8 * k)) & 0xFFu);
+                const float fxk = float((qfx >> (8 * k)) & 0xFFu), fyk = float((qfy >> (8 * k)) & 0xFFu), fzk = float((qfz >> (8 * k)) & 0xFFu);
+                const float tn = fmaxf(fmaxf(fmaf(nxk, ax, bx), fmaf(nyk, ay, by)), fmaxf(fmaf(nzk, az, bz), 0.0f));
+                const float tf = fminf(fminf(fmaf(fxk, ax, bx), fmaf(fyk, ay, by)), fminf(fmaf(fzk, az, bz), tmax32));
+                nr[k] = ((tn <= tf) && ch[k] != kEmptyChild) ? tn : miss;
+            }
+#define RT_CE(a, b)                                                   \
+    if (nr[a] > nr[b]) {                                              \
+        float tn_ = nr[a]; nr[a] = nr[b]; nr[b] = tn_;                \
+        int32_t tc_ = ch[a]; ch[a] = ch[b]; ch[b] = tc_;              \
+    }
+            RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2) RT_CE(1, 3) RT_CE(1, 2)
+#undef RT_CE
+            if (nr[0] < miss) {
+                // farthest first, so that the nearest remaining child is popped first
+                if (nr[3] < miss) { gc.stack[sp * 256] = (static_cast<unsigned long long>(__float_as_uint(nr[3])) << 32) | uint32_t(ch[3]); sp++; }
+                if (nr[2] < miss) { gc.stack[sp * 256] = (static_cast<unsigned long long>(__float_as_uint(nr[2])) << 32) | uint32_t(ch[2]); sp++; }
+                if (nr[1] < miss) { gc.stack[sp * 256] = (static_cast<unsigned long long>(__float_as_uint(nr[1])) << 32) | uint32_t(ch[1]); sp++; }
+                node = ch[0];
+            } else {
+                pop = true;
+            }
+        } else {
+            const uint32_t code = uint32_t(~node);
+            const uint32_t first = code >> 3, count = (code & 7u) + 1u;
+            for (uint32_t i = 0; i < count; i++) {
+                const GroupPrimRef ref = sc.group_prims[first + i];
+                bool reachable = true;  // the reference's ancestor boxes that do not contain this primitive still stand in front of it
+                for (int32_t k = 0; k < ref.guard_count; k++)
+                    reachable = reachable && test_bounding_box(sc.bounds[sc.group_guards[ref.guard_first + k]], cur, t_lo, best.t);
+                if (!reachable) continue;
+                const Op pop_ = sc.ops[ref.pc];
+                if (STATS) cnt.prim_tests++;
+                if (pop_.type == OP_SPHERE) {
+                    R t;
+                    if (sphere_test<R, true>(sc.spheres[pop_.arg], cur, t_lo, best.t, t) && hit_takes_over(sc, t, pop_, best)) { best.t = t; best.pc = ref.pc; }
+                } else {
+                    R t, u, v;
+                    if (plane_test<R, true>(sc.planes[pop_.arg], cur, t_lo, best.t, t, u, v) && hit_takes_over(sc, t, pop_, best)) { best.t = t; best.pc = ref.pc; best.u = u; best.v = v; }
+                }
+            }
+            tmax32 = f32_at_least(best.t - t_shift);
+            pop = true;
+        }
+        if (pop) {
+            for (;;) {
+                if (sp == 0) return;
+                sp--;
+                const unsigned long long e = gc.stack[sp * 256];
+                if (__uint_as_float(uint32_t(e >> 32)) <= tmax32) {
+                    node = int32_t(uint32_t(e));
+                    break;
+                }
+            }
+        }
+    }
+}
+
 // The scene program over everything except the deferred mesh ops: closest hit of `wray` with the spheres /
 // quads / sky / sun in `best`; returns true if the ray also has to visit a mesh (its object-space ray enters a
 // mesh's box inside the interval the primitives visited before it left).  Every lane walks the same program.
@@ -453,12 +541,12 @@ __global__ void __launch_bounds__(256, RT_ISECT_WAVES) k_wf_intersect(SceneView<
 // volume.rs:33-71, as in world_test / k_wf_intersect) whose boundaries are made of spheres and quads, and every mesh op
 // comes AFTER the last volume: a volume's draw depends on the closest hit so far (volume.rs:40-43), so a mesh in front
 // of it cannot be deferred (such scenes, and meshes inside a boundary, use the combined kernel).
-template <typename R, bool STATS, bool VOL = false>
-RT_DEV bool prims_search(const SceneView<R>& sc, const Ray<R>& wray, Best<R>& best, LaneCounters& cnt, Rng* rng = nullptr) {
+// GROUPS: OP_GROUP ops are served by group_search (their op form behind them is skipped); otherwise they are no-ops.
+template <typename R, bool STATS, bool VOL = false, bool GROUPS = false>
+RT_DEV bool prims_search(const SceneView<R>& sc, const Ray<R>& wray, Best<R>& best, LaneCounters& cnt, Rng* rng = nullptr, const GroupCtx* gc = nullptr) {
     const R t_lo_outer = R(0.001);
     R t_lo = t_lo_outer;     // changes only inside a volume's boundary searches
-    Best<R> saved{};         // VOL: the caller's search state during a boundary search
-    R vol_enter = R(0);
+    VolFrames<R> vol;        // VOL: the callers' search states during boundary searches
     Ray<R> cur = wray;
     best.t = Lim<R>::inf(); best.pc = -1; best.tri = -1; best.u = R(0); best.v = R(0);
     bool to_mesh = false;
@@ -468,52 +556,25 @@ RT_DEV bool prims_search(const SceneView<R>& sc, const Ray<R>& wray, Best<R>& be
         const Op op = sc.ops[pc];
         if (op.type == OP_END) break;
         switch (op.type) {
-            case OP_VOL_BEGIN:  // volume.rs:34: boundary.test(ray, Interval::UNIVERSE)
-                if constexpr (VOL) {
-                    saved = best;
-                    best.t = Lim<R>::inf();
-                    best.pc = -1;
-                    t_lo = -Lim<R>::inf();
-                }
+            case OP_VOL_BEGIN:
+                if constexpr (VOL) vol_begin(vol, best, t_lo);
                 break;
-            case OP_VOL_MID:  // volume.rs:35-37: second search over (t_enter + 0.0001, inf)
+            case OP_VOL_MID:
                 if constexpr (VOL) {
-                    if (best.pc < 0) {
-                        best = saved;
-                        t_lo = t_lo_outer;
+                    if (vol_mid(vol, best, t_lo)) {
                         pc = op.skip;
                         continue;
                     }
-                    vol_enter = best.t;
-                    t_lo = vol_enter + R(0.0001);
-                    best.t = Lim<R>::inf();
-                    best.pc = -1;
                 }
                 break;
-            case OP_VOL_END:  // volume.rs:38-68
-                if constexpr (VOL) {
-                    const bool has_exit = best.pc >= 0;
-                    const R t_exit = best.t;
-                    best = saved;
-                    t_lo = t_lo_outer;
-                    if (has_exit) {
-                        R t_min = fmax(vol_enter, t_lo_outer);
-                        R t_max = fmin(t_exit, best.t);
-                        if (!(t_min >= t_max)) {
-                            t_min = fmax(t_min, R(0));
-                            R ray_len = length(cur.d);
-                            R dist_inside = (t_max - t_min) * ray_len;
-                            R uu = rng_uniform<R>(*rng);
-                            R hit_dist = sc.volumes[op.arg].neg_inv_density * (uu == R(0) ? -Lim<R>::inf() : log_r(uu));
-                            if (!(hit_dist > dist_inside)) {
-                                best.t = t_min + hit_dist / ray_len;
-                                best.pc = pc;
-                                best.tri = -1;
-                                best.u = R(0);
-                                best.v = R(0);
-                            }
-                        }
-                    }
+            case OP_VOL_END:
+                if constexpr (VOL) vol_end(sc, vol, best, t_lo, cur, op, pc, *rng);
+                break;
+            case OP_GROUP:
+                if constexpr (GROUPS) {
+                    group_search<R, STATS>(sc, *gc, sc.groups[op.arg], cur, t_lo, best, cnt);
+                    pc = op.skip;
+                    continue;
                 }
                 break;
             case OP_BOUNDS:
@@ -587,14 +648,27 @@ RT_DEV bool prims_search(const SceneView<R>& sc, const Ray<R>& wray, Best<R>& be
 #define RT_PRIMS_WAVES 5  // 95 VGPRs without scratch since the mesh-box test moved to the mesh op (round 2); 4 waves before: 171 -> 157 ms per step
 #endif
 // LDS: 0 = tables in global memory, 1 = all small tables staged in LDS, 2 = a prefix of them (see scene_tables_to_lds)
-template <typename R, bool STATS, int LDS, bool VOL>
-__global__ void __launch_bounds__(256, VOL ? 3 : RT_PRIMS_WAVES) k_wf_prims(SceneView<R> sc_g, WfPool<R> pool, const uint32_t* __restrict__ queue,
+// GROUPS: the scene has re-built primitive groups (OP_GROUP): their BVH nodes and a per-lane traversal stack of `group_levels`
+// entries live in LDS behind the mesh list.
+template <typename R, bool STATS, int LDS, bool VOL, bool GROUPS>
+__global__ void __launch_bounds__(256, VOL ? 2 : (GROUPS ? 3 : RT_PRIMS_WAVES)) k_wf_prims(SceneView<R> sc_g, WfPool<R> pool, const uint32_t* __restrict__ queue,
                                                   uint32_t* __restrict__ mesh_queue, WfCounters* __restrict__ ctr,
-                                                  DeviceCounters* counters, uint32_t staged) {
+                                                  DeviceCounters* counters, uint32_t staged, uint32_t group_levels) {
     extern __shared__ __align__(16) char lds_raw[];
     uint32_t* mesh_list = reinterpret_cast<uint32_t*>(lds_raw);  // [WF_CHUNK]
     uint32_t* lc = mesh_list + WF_CHUNK;                        // [0] list length, [1] queue base
     char* tables = reinterpret_cast<char*>(lc + 4);
+    GroupCtx gc{};
+    if constexpr (GROUPS) {
+        gc.stack = (LdsU64*)(reinterpret_cast<unsigned long long*>(tables) + threadIdx.x);
+        tables += size_t(group_levels) * 256 * 8;
+        uint4* dst = reinterpret_cast<uint4*>(tables);
+        const uint4* src = reinterpret_cast<const uint4*>(sc_g.group_nodes);
+        const uint32_t n16 = uint32_t(sc_g.n_group_nodes) * uint32_t(sizeof(BvhNode4q) / 16);
+        for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+        gc.nodes = reinterpret_cast<const BvhNode4q*>(dst);
+        tables += size_t(n16) * 16;
+    }
     if (threadIdx.x < 4) lc[threadIdx.x] = 0;
     SceneView<R> sc = sc_g;
     if constexpr (LDS == 1) sc = scene_tables_to_lds<R, true>(sc_g, sc_g.lay, sc_g.small_blob, tables, staged);
@@ -616,10 +690,10 @@ __global__ void __launch_bounds__(256, VOL ? 3 : RT_PRIMS_WAVES) k_wf_prims(Scen
             if constexpr (VOL) {  // Volume::test draws the free-flight distance from the path's stream (volume.rs:47)
                 Rng rng;
                 rng.s = at(pool.rng, slot);
-                to_mesh = prims_search<R, STATS, true>(sc, wray, best, cnt, &rng);
+                to_mesh = prims_search<R, STATS, true, false>(sc, wray, best, cnt, &rng);
                 at(pool.rng, slot) = rng.s;
             } else {
-                to_mesh = prims_search<R, STATS>(sc, wray, best, cnt);
+                to_mesh = prims_search<R, STATS, false, GROUPS>(sc, wray, best, cnt, nullptr, &gc);
             }
             at(pool.ht, slot) = best.t; at(pool.hu, slot) = best.u; at(pool.hv, slot) = best.v;
             at(pool.hpc, slot) = best.pc; at(pool.htri, slot) = best.tri;
@@ -642,13 +716,6 @@ __global__ void __launch_bounds__(256, VOL ? 3 : RT_PRIMS_WAVES) k_wf_prims(Scen
     }
 }
 
-// f32 value that is certainly >= x (x finite or +inf): round to nearest, then add a relative margin.
-RT_DEV float f32_at_least(double x) {
-    float f = float(x);
-    return f + fabsf(f) * 9.5367431640625e-7f + 1e-30f;  // 2^-20 relative
-}
-RT_DEV float f32_at_least(float x) { return x + fabsf(x) * 9.5367431640625e-7f + 1e-30f; }
-
 // Per-lane traversal stack of k_wf_mesh: entries are (child reference, f32 entry distance of its box).
 // The first `lds_levels` levels live in LDS (`[level][lane]`, conflict-free 8-B accesses), deeper levels in
 // a private global spill area (`[level][global lane]`, coalesced).  A shallow LDS part keeps 4 blocks per CU
@@ -657,7 +724,6 @@ RT_DEV float f32_at_least(float x) { return x + fabsf(x) * 9.5367431640625e-7f +
 // The LDS part is addressed through an LDS-qualified pointer: with plain (generic) pointers hipcc merges the two stores of
 // `put` into one store through a selected pointer and then fails in the backend ("Illegal instruction detected:
 // V_CMP_NE_U32 0, src_shared_base") once a node step has more than a few puts (the 8-wide node has seven).
-typedef __attribute__((address_space(3))) unsigned long long LdsU64;
 struct MeshStack {
     LdsU64* lds;       // + threadIdx.x
     uint2* spill;      // + global lane
@@ -679,7 +745,11 @@ struct MeshStack {
 template <typename R> constexpr uint32_t kMeshWaveLds = 1024u + 3u * 64u * uint32_t(sizeof(R));  // per wave, see k_wf_mesh
 
 // NODE: 0 = 4-wide f32 nodes (BvhNode4f, 128 B), 1 = 4-wide quantised nodes (BvhNode4q, 64 B)
-template <typename R, bool STATS, int NODE>
+// MULTI: the program has more than one mesh op: a lane serves the mesh ops of its path one after the other (per-lane mesh
+// cursor, one op entered per trip with wave-uniform records).  false: the one mesh op's record sits in SGPRs for the whole
+// kernel and none of that bookkeeping exists - the general form costs the single-mesh headline scene 16 % more vector
+// instructions and 4 % of the kernel's time (profiles/r03/ab/multi_mesh_kernel.txt), so both are kept.
+template <typename R, bool STATS, int NODE, bool MULTI>
 __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc, WfPool<R> pool, const uint32_t* __restrict__ mesh_queue,
                                                                  WfCounters* __restrict__ ctr, DeviceCounters* counters,
                                                                  uint32_t refill_min, uint32_t inner_min,
@@ -707,6 +777,17 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
     const uint32_t n_mesh_ops = uint32_t(sc.n_mesh_ops);
     const R big = sizeof(R) == 8 ? R(1e150) : R(1e18);
     const MeshOpRec<R>* mrecs = sc.mesh_op_recs;
+    // Loads record m (wave-uniform index) with scalar loads, field by field (no copy constructor from an address space).
+    auto load_rec = [&](uint32_t m, MeshOpRec<R>& rb) {
+        const auto* rec = as_const_mem(mrecs) + m;
+        rb.pc = rec->pc; rb.chain = rec->chain; rb.node4_base = rec->node4_base; rb.flags = rec->flags;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { rb.lo[a] = rec->lo[a]; rb.hi[a] = rec->hi[a]; }
+#pragma unroll
+        for (int k = 0; k < 12; k++) rb.inv[k] = rec->inv[k];
+    };
+    MeshOpRec<R> rb0;  // !MULTI: the one mesh op, for the whole kernel
+    if constexpr (!MULTI) load_rec(0u, rb0);
     LaneCounters cnt;
     uint32_t w_node = 0, w_tri = 0, w_refill = 0, l_refill = 0, l_culled = 0;  // STATS: see DeviceCounters
     bool has = false;        // this lane is inside a mesh's BVH
@@ -727,118 +808,174 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
 
     // The lane has finished every mesh of its path: the closest triangle, if one beat the other primitives' hit, is the path's hit.
     auto finish_path = [&]() {
-        const uint32_t hm = (mcur >> 15) & 0x7FFFu;
-        if (hm != 0u) {
-            at(pool.ht, slot) = t_max; at(pool.hu, slot) = hit_u; at(pool.hv, slot) = hit_v;
-            at(pool.hpc, slot) = sc.mesh_ops[hm - 1u]; at(pool.htri, slot) = hit_tri;
+        if constexpr (MULTI) {
+            const uint32_t hm = (mcur >> 15) & 0x7FFFu;
+            if (hm != 0u) {
+                at(pool.ht, slot) = t_max; at(pool.hu, slot) = hit_u; at(pool.hv, slot) = hit_v;
+                at(pool.hpc, slot) = sc.mesh_ops[hm - 1u]; at(pool.htri, slot) = hit_tri;
+            }
+        } else {
+            if (hit_tri >= 0) {  // a triangle beat the other primitives' hit
+                at(pool.ht, slot) = t_max; at(pool.hu, slot) = hit_u; at(pool.hv, slot) = hit_v;
+                at(pool.hpc, slot) = rb0.pc; at(pool.htri, slot) = hit_tri;
+            }
         }
     };
     // Pops entries until one whose box can still contain a closer hit is found (entry distance <= current
     // bound); a lane whose stack runs empty has finished this mesh and goes on to the path's next mesh op.
+    // (The end-of-mesh bookkeeping stands BEHIND the pop loop: inside it, it was if-converted into every trip of the loop -
+    // 3.3 G culled pops per headline step - and cost the kernel 12 % more vector instructions than the single-mesh form.)
     auto pop_next = [&]() {
-        for (;;) {
-            if (sp == 0) {
+        if constexpr (MULTI) {
+            bool found_entry = false;
+            while (sp > 0) {
+                sp--;
+                const uint2 e = stk.get(sp);
+                if (__uint_as_float(e.y) <= tmax32) {
+                    node = int32_t(e.x);
+                    found_entry = true;
+                    break;
+                }
+                if (STATS) l_culled++;
+            }
+            if (!found_entry) {
                 has = false;
                 mcur = (mcur & 0x7FFFFFFFu) + 1u;
                 if ((mcur & 0x7FFFu) < n_mesh_ops) pending = true;
                 else finish_path();
-                return;
             }
-            sp--;
-            uint2 e = stk.get(sp);
-            if (__uint_as_float(e.y) <= tmax32) {
-                node = int32_t(e.x);
-                return;
+        } else {
+            for (;;) {
+                if (sp == 0) {
+                    has = false;
+                    finish_path();
+                    return;
+                }
+                sp--;
+                const uint2 e = stk.get(sp);
+                if (__uint_as_float(e.y) <= tmax32) {
+                    node = int32_t(e.x);
+                    return;
+                }
+                if (STATS) l_culled++;
             }
-            if (STATS) l_culled++;
         }
+    };
+    // Enters the mesh of record `rb` with this lane's path: object-space ray, search bound, entry into the mesh's box, f32
+    // culling ray.  Returns false if the ray misses the box inside its interval (MULTI only: k_wf_prims has already asked that
+    // question for the single mesh).
+    auto enter_mesh = [&](const MeshOpRec<R>& rb) -> bool {
+        const int32_t mpc = rb.pc;
+        Ray<R> wray = make_ray(mk<R>(at(pool.ox, slot), at(pool.oy, slot), at(pool.oz, slot)), mk<R>(at(pool.dx, slot), at(pool.dy, slot), at(pool.dz, slot)));
+        Ray<R> ray;
+        const uint32_t n_chain = rb.flags >> 16;
+        if (n_chain == 0u) ray = wray;
+        else if (n_chain == 1u) ray = make_ray(xform_apply(rb.inv, wray.o, R(1)), xform_apply(rb.inv, wray.d, R(0)));  // transform.rs:124-127
+        else ray = ray_in_chain_uniform(sc, wray, rb.chain);
+        o = ray.o;
+        d = ray.d;
+        V3<R> inv = mk<R>(R(fabs(ray.inv.x) > big ? copysign(big, ray.inv.x) : ray.inv.x),
+                          R(fabs(ray.inv.y) > big ? copysign(big, ray.inv.y) : ray.inv.y),
+                          R(fabs(ray.inv.z) > big ? copysign(big, ray.inv.z) : ray.inv.z));
+        // The other primitives' closest hit bounds the search.  At exactly equal t the op that comes first in
+        // program order wins: if that is this mesh, t == bound must be accepted.  A triangle of an EARLIER mesh
+        // always wins a tie (strict bound, like the reference's shrinking interval: list.rs:58-74).
+        const R bound = at(pool.ht, slot);
+        const int32_t bpc = at(pool.hpc, slot);
+        const R excl = (bpc > mpc && bound < Lim<R>::inf()) ? nextafter(bound, Lim<R>::inf()) : bound;
+        if constexpr (MULTI) t_max = ((mcur >> 15) & 0x7FFFu) != 0u ? fmin(t_max, excl) : excl;
+        else t_max = excl;
+        // entry into the mesh box (>= 0) and exit; the culling origin is o + d * t_shift
+        R e0x = (rb.lo[0] - o.x) * inv.x, e1x = (rb.hi[0] - o.x) * inv.x;
+        R e0y = (rb.lo[1] - o.y) * inv.y, e1y = (rb.hi[1] - o.y) * inv.y;
+        R e0z = (rb.lo[2] - o.z) * inv.z, e1z = (rb.hi[2] - o.z) * inv.z;
+        t_shift = fmax(fmax(fmin(e0x, e1x), fmin(e0y, e1y)), fmax(fmin(e0z, e1z), R(0)));
+        if constexpr (MULTI) {
+            R t_exit = fmin(fmin(fmax(e0x, e1x), fmax(e0y, e1y)), fmax(e0z, e1z));
+            // a miss only if it is one with a few ulps of slack on both ends (a NaN compares false: the mesh is entered)
+            const R eps = Lim<R>::eps() * R(16);
+            if ((t_shift - fabs(t_shift) * eps > t_exit + fabs(t_exit) * eps) || (t_shift - fabs(t_shift) * eps > t_max) || !(rb.lo[0] <= rb.hi[0])) return false;
+        }
+        if (!(t_shift < Lim<R>::inf())) t_shift = R(0);
+        V3<R> oc = o + d * t_shift;
+        const float big32 = 1e18f;
+        float dx32 = float(d.x), dy32 = float(d.y), dz32 = float(d.z);
+        ivx = 1.0f / dx32; ivy = 1.0f / dy32; ivz = 1.0f / dz32;
+        ivx = fabsf(ivx) > big32 ? copysignf(big32, ivx) : ivx;
+        ivy = fabsf(ivy) > big32 ? copysignf(big32, ivy) : ivy;
+        ivz = fabsf(ivz) > big32 ? copysignf(big32, ivz) : ivz;
+        oix = float(oc.x) * ivx; oiy = float(oc.y) * ivy; oiz = float(oc.z) * ivz;
+        tmax32 = f32_at_least(t_max - t_shift);
+        node = int32_t(rb.node4_base);
+        sp = 0;
+        return true;
     };
 
     for (;;) {
-        // ---- refill: lanes without a path take a queue entry; lanes between two meshes of their path enter the next one ----
-        const unsigned long long idle = __ballot(!has);
-        const unsigned long long waiting = __ballot(pending);
-        if ((uint32_t(__popcll(idle)) >= refill_min && (!exhausted || waiting != 0ull)) || (waiting != 0ull && idle == ~0ull)) {
-            const unsigned long long want = __ballot(!has && !pending);
-            if (!exhausted && want != 0ull) {
-                uint32_t my = 0;
-                if (STATS) w_refill++;
-                if (wave_fetch(range, want, cursor_ptr, n, exhausted, my)) {
-                    if (STATS) l_refill++;
-                    slot = mesh_queue[my];
-                    mcur = 0;
-                    hit_tri = -1;
-                    pending = true;
+        if constexpr (MULTI) {
+            // ---- refill: lanes without a path take a queue entry; lanes between two meshes of their path enter the next one ----
+            const unsigned long long idle = __ballot(!has);
+            const unsigned long long waiting = __ballot(pending);
+            if ((uint32_t(__popcll(idle)) >= refill_min && (!exhausted || waiting != 0ull)) || (waiting != 0ull && idle == ~0ull)) {
+                const unsigned long long want = __ballot(!has && !pending);
+                if (!exhausted && want != 0ull) {
+                    uint32_t my = 0;
+                    if (STATS) w_refill++;
+                    if (wave_fetch(range, want, cursor_ptr, n, exhausted, my)) {
+                        if (STATS) l_refill++;
+                        slot = mesh_queue[my];
+                        mcur = 0;
+                        hit_tri = -1;
+                        pending = true;
+                    }
                 }
-            }
-            // Enter the path's next mesh: its object-space ray against the mesh's box, inside the interval that the other
-            // primitives (k_wf_prims) and the meshes visited before left.  Lanes whose ray misses the box try the op after it.
-            // One mesh op per trip - the one the first waiting lane wants - so that its record, transform chain and matrices
-            // are wave-uniform: scalar loads into SGPRs, as when the kernel served a single mesh.  (Per-lane records cost
-            // every refill four dependent vector-memory round trips: +8 % on the whole kernel.)
-            for (;;) {
-                const unsigned long long pend = __ballot(pending);
-                if (pend == 0ull) break;
-                const uint32_t m = uint32_t(__builtin_amdgcn_readfirstlane(int(__shfl(int(mcur & 0x7FFFu), __ffsll((long long)pend) - 1))));
-                MeshOpRec<R> rb;  // wave-uniform: scalar loads into SGPRs (field by field: no copy constructor from an address space)
-                {
-                    const auto* rec = as_const_mem(mrecs) + m;
-                    rb.pc = rec->pc; rb.chain = rec->chain; rb.node4_base = rec->node4_base; rb.flags = rec->flags;
-#pragma unroll
-                    for (int a = 0; a < 3; a++) { rb.lo[a] = rec->lo[a]; rb.hi[a] = rec->hi[a]; }
-                }
-                if (pending && (mcur & 0x7FFFu) == m) {
-                    const int32_t mpc = rb.pc;
-                    Ray<R> wray = make_ray(mk<R>(at(pool.ox, slot), at(pool.oy, slot), at(pool.oz, slot)), mk<R>(at(pool.dx, slot), at(pool.dy, slot), at(pool.dz, slot)));
-                    Ray<R> ray = ray_in_chain_uniform(sc, wray, rb.chain);
-                    o = ray.o;
-                    d = ray.d;
-                    V3<R> inv = {fabs(ray.inv.x) > big ? copysign(big, ray.inv.x) : ray.inv.x,
-                                 fabs(ray.inv.y) > big ? copysign(big, ray.inv.y) : ray.inv.y,
-                                 fabs(ray.inv.z) > big ? copysign(big, ray.inv.z) : ray.inv.z};
-                    // The other primitives' closest hit bounds the search.  At exactly equal t the op that comes first in
-                    // program order wins: if that is this mesh, t == bound must be accepted.  A triangle of an EARLIER mesh
-                    // always wins a tie (strict bound, like the reference's shrinking interval: list.rs:58-74).
-                    const R bound = at(pool.ht, slot);
-                    const int32_t bpc = at(pool.hpc, slot);
-                    const R excl = (bpc > mpc && bound < Lim<R>::inf()) ? nextafter(bound, Lim<R>::inf()) : bound;
-                    t_max = ((mcur >> 15) & 0x7FFFu) != 0u ? fmin(t_max, excl) : excl;
-                    // entry into the mesh box (>= 0) and exit; the culling origin is o + d * t_shift
-                    R e0x = (rb.lo[0] - o.x) * inv.x, e1x = (rb.hi[0] - o.x) * inv.x;
-                    R e0y = (rb.lo[1] - o.y) * inv.y, e1y = (rb.hi[1] - o.y) * inv.y;
-                    R e0z = (rb.lo[2] - o.z) * inv.z, e1z = (rb.hi[2] - o.z) * inv.z;
-                    t_shift = fmax(fmax(fmin(e0x, e1x), fmin(e0y, e1y)), fmax(fmin(e0z, e1z), R(0)));
-                    R t_exit = fmin(fmin(fmax(e0x, e1x), fmax(e0y, e1y)), fmax(e0z, e1z));
-                    // a miss only if it is one with a few ulps of slack on both ends (a NaN compares false: the mesh is entered)
-                    const R eps = Lim<R>::eps() * R(16);
-                    const bool miss = (t_shift - fabs(t_shift) * eps > t_exit + fabs(t_exit) * eps) || (t_shift - fabs(t_shift) * eps > t_max) || !(rb.lo[0] <= rb.hi[0]);
-                    if (miss) {
-                        mcur++;
-                        if ((mcur & 0x7FFFu) >= n_mesh_ops) { pending = false; finish_path(); }
-                    } else {
-                        if (!(t_shift < Lim<R>::inf())) t_shift = R(0);
-                        V3<R> oc = o + d * t_shift;
-                        const float big32 = 1e18f;
-                        float dx32 = float(d.x), dy32 = float(d.y), dz32 = float(d.z);
-                        ivx = 1.0f / dx32; ivy = 1.0f / dy32; ivz = 1.0f / dz32;
-                        ivx = fabsf(ivx) > big32 ? copysignf(big32, ivx) : ivx;
-                        ivy = fabsf(ivy) > big32 ? copysignf(big32, ivy) : ivy;
-                        ivz = fabsf(ivz) > big32 ? copysignf(big32, ivz) : ivz;
-                        oix = float(oc.x) * ivx; oiy = float(oc.y) * ivy; oiz = float(oc.z) * ivz;
-                        tmax32 = f32_at_least(t_max - t_shift);
-                        node = int32_t(rb.node4_base);
-                        sp = 0;
-                        if (rb.flags & RT_MESH_HIT_BACK_FACES) mcur |= 0x80000000u;
-                        has = true;
-                        pending = false;
-                        if (STATS) cnt.mesh_rays++;
+                // Enter the path's next mesh: its object-space ray against the mesh's box, inside the interval that the other
+                // primitives (k_wf_prims) and the meshes visited before left.  Lanes whose ray misses the box try the op after it.
+                // One mesh op per trip - the one the first waiting lane wants - so that its record (bounds, transform) is
+                // wave-uniform: scalar loads into SGPRs.  (Per-lane records cost every refill four dependent vector-memory
+                // round trips.)
+                for (;;) {
+                    const unsigned long long pend = __ballot(pending);
+                    if (pend == 0ull) break;
+                    const uint32_t m = uint32_t(__builtin_amdgcn_readfirstlane(int(__shfl(int(mcur & 0x7FFFu), __ffsll((long long)pend) - 1))));
+                    MeshOpRec<R> rb;
+                    load_rec(m, rb);
+                    if (pending && (mcur & 0x7FFFu) == m) {
+                        if (!enter_mesh(rb)) {
+                            mcur++;
+                            if ((mcur & 0x7FFFu) >= n_mesh_ops) { pending = false; finish_path(); }
+                        } else {
+                            if (rb.flags & RT_MESH_HIT_BACK_FACES) mcur |= 0x80000000u;
+                            has = true;
+                            pending = false;
+                            if (STATS) cnt.mesh_rays++;
+                        }
                     }
                 }
             }
-        }
-        if (__ballot(has) == 0ull) {
-            if (exhausted && __ballot(pending) == 0ull) break;
-            continue;
+            if (__ballot(has) == 0ull) {
+                if (exhausted && __ballot(pending) == 0ull) break;
+                continue;
+            }
+        } else {
+            // ---- refill ----
+            const unsigned long long idle = __ballot(!has);
+            if (!exhausted && uint32_t(__popcll(idle)) >= refill_min) {
+                uint32_t my = 0;
+                if (STATS) w_refill++;
+                if (wave_fetch(range, idle, cursor_ptr, n, exhausted, my)) {
+                    if (STATS) l_refill++;
+                    slot = mesh_queue[my];
+                    hit_tri = -1;
+                    enter_mesh(rb0);
+                    has = true;
+                    if (STATS) cnt.mesh_rays++;
+                }
+            }
+            if (__ballot(has) == 0ull) {
+                if (exhausted) break;
+                continue;
+            }
         }
         // ---- inner nodes: descend until (nearly) every lane holds a leaf or has finished ----
         for (;;) {
@@ -947,9 +1084,16 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
                     const uint32_t k = e >> 8;
                     const V3<R> po = {__shfl(o.x, owner), __shfl(o.y, owner), __shfl(o.z, owner)};
                     const V3<R> pd = {__shfl(d.x, owner), __shfl(d.y, owner), __shfl(d.z, owner)};
-                    const uint32_t pfirst_hb = uint32_t(__shfl(int(first | (mcur & 0x80000000u)), owner));  // bit 31: the owner's mesh hits back faces
-                    const uint32_t pfirst = pfirst_hb & 0x7FFFFFFFu;
-                    const bool hit_back = (pfirst_hb >> 31) != 0u;
+                    uint32_t pfirst;
+                    bool hit_back;
+                    if constexpr (MULTI) {
+                        const uint32_t pfirst_hb = uint32_t(__shfl(int(first | (mcur & 0x80000000u)), owner));  // bit 31: the owner's mesh hits back faces
+                        pfirst = pfirst_hb & 0x7FFFFFFFu;
+                        hit_back = (pfirst_hb >> 31) != 0u;
+                    } else {
+                        pfirst = uint32_t(__shfl(int(first), owner));
+                        hit_back = (rb0.flags & RT_MESH_HIT_BACK_FACES) != 0u;
+                    }
                     R rt = Lim<R>::inf(), ru = R(0), rv = R(0);  // t = +inf: "no hit" (fails `t_max <= t` at the owner)
                     if (act) {
                         const TriRec<R>& tr = tris[pfirst + k];
@@ -984,7 +1128,7 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
                             if (t <= t_lo || t_max <= t) continue;
                             t_max = t; hit_u = res_u[idx]; hit_v = res_v[idx];
                             hit_tri = int32_t(first + uint32_t(j));
-                            mcur = (mcur & 0xC0007FFFu) | (((mcur & 0x7FFFu) + 1u) << 15);
+                            if constexpr (MULTI) mcur = (mcur & 0xC0007FFFu) | (((mcur & 0x7FFFu) + 1u) << 15);
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -1020,6 +1164,9 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
 // 5 waves (96 VGPRs + 16 B of scratch) are slower.  The texture-interpreter variants need 174-189: no cap for them.
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4
+#endif
+#ifndef RT_SHADE_PREFETCH
+#define RT_SHADE_PREFETCH 0  // 1: touch the next trip's triangle attributes one trip ahead (A/B build: -DRT_SHADE_PREFETCH=1)
 #endif
 #define RT_SHADE_BOUNDS __launch_bounds__(256, TEX ? 1 : RT_SHADE_WAVES)
 
@@ -1065,12 +1212,25 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
     unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
 #endif
     // ---- phase 1: one path vertex per lane, chunk by chunk ----
+    uint32_t touched = 0;  // see the prefetch below
     for (uint32_t base = begin; base < end; base += blockDim.x) {
         const uint32_t i = base + threadIdx.x;
         const bool active = i < end;
         bool alive = false;
         uint32_t slot = 0;
         RT_STAMP(0);
+        // Touch the shading attributes of the NEXT trip's mesh hits now: resolve_hit fetches them (128 B per triangle, random)
+        // as the last link of a chain  slot -> hit record -> triangle -> attributes  and nearly every wave holds a mesh hit,
+        // so every trip used to wait for a fetch from HBM.  One dword per 64-B half pulls the line into this XCD's L2 a whole
+        // trip ahead; the values only feed a word that is never stored.
+        if (RT_SHADE_PREFETCH && i + blockDim.x < end) {
+            const uint32_t nslot = full ? i + blockDim.x : queue_in[i + blockDim.x];
+            const int32_t ntri = at(pool.htri, nslot);
+            if (ntri >= 0) {
+                const uint32_t* a = reinterpret_cast<const uint32_t*>(sc.attrs + ntri);
+                touched ^= a[0] ^ a[sizeof(TriAttr<R>) / 8];
+            }
+        }
         if (active) {
             slot = full ? i : queue_in[i];
             PathState<R> ps;
@@ -1172,6 +1332,7 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
     __syncthreads();
     const uint32_t qb = lc[4];
     for (uint32_t j = threadIdx.x; j < n_alive; j += blockDim.x) queue_out[qb + j] = alive_list[j];
+    if (RT_SHADE_PREFETCH && touched == 0x9E3779B9u && n == 0xFFFFFFFFu) lc[7] = touched;  // keeps the touches alive; never true
     RT_STAMP(6);
 #ifdef RT_SHADE_STAMPS
     if ((threadIdx.x & 63u) == 0) {

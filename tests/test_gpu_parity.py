@@ -35,14 +35,22 @@ SCENES = {
     "single_light": ["tests/scenes/single_light", "-w=37", "-s=9", "--seed=8"],     # width not a tile multiple
     "test": ["scenes/test", "-w=45", "-s=16", "--seed=9"],
     "tonemap_test": ["scenes/tonemap_test", "-w=40", "-s=16", "--seed=10"],
-    "two_meshes": ["tests/scenes/two_meshes", "-w=48", "-s=16", "--seed=11"],   # >1 mesh op: combined intersect kernel
+    "two_meshes": ["tests/scenes/two_meshes", "-w=48", "-s=16", "--seed=11"],   # >1 mesh op: k_wf_mesh serves a path's meshes one after the other
     # texture interpreter variants of the kernels (image / noise / lerp / channel textures, normal maps)
     "perlin": ["scenes/perlin", "-w=48", "-s=16", "--seed=12"],
     "earth": ["scenes/earth", "-w=48", "-s=16", "--seed=13"],          # JPEG texture on a sphere
     "texture_test": ["scenes/texture_test", "-w=48", "-s=16", "--seed=14"],  # PNG albedo / roughness channel / normal map on a mesh
     "texture_mix": ["tests/scenes/texture_mix", "-w=48", "-s=16", "--seed=15"],  # every operator, every primitive's tangent frame
-    # constant-density volumes (sphere / mesh / box boundaries); wavefront: combined intersect kernel, VOL variant
+    # constant-density volumes (sphere / mesh / box boundaries); wavefront: combined intersect kernel, VOL variant (a mesh in a boundary)
     "smoke": ["tests/scenes/smoke", "-w=48", "-s=16", "--seed=16"],
+    # the reference's cornell_smoke: box boundaries only -> the volumes run inside k_wf_prims (VOL variant)
+    "cornell_smoke": ["scenes/cornell_smoke", "-w=48", "-s=16", "--seed=21"],
+    # a volume inside another volume's boundary, a plain volume, and a mesh BEHIND them (k_wf_prims<VOL> + k_wf_mesh)
+    "nested_volumes": ["tests/scenes/nested_volumes", "-w=48", "-s=16", "--seed=22"],
+    # ObjectLists three levels deep inside `lights` (with an empty list and a non-light member)
+    "nested_lights": ["tests/scenes/nested_lights", "-w=48", "-s=16", "--seed=23"],
+    # a texture expression with more live values than the interpreter's four registers (spilled stack)
+    "deep_texture": ["tests/scenes/deep_texture", "-w=48", "-s=16", "--seed=24"],
     # an ObjectList (emissive box) inside `lights`: nested pdf_value / random
     "box_light": ["tests/scenes/box_light", "-w=48", "-s=16", "--seed=17"],
     # zero-weight vertices (black albedo, light samples below the horizon) in front of 0/0 vertices (one-sided light seen
@@ -225,7 +233,7 @@ def test_f32_is_statistically_equivalent(dev, name):
     assert close.mean() >= 0.95, f"only {close.mean():.3%} of f32 values are close to the f64 oracle"
 
 
-@pytest.mark.parametrize("name", ["cornell", "hollow_glass", "default", "light_test", "two_meshes", "texture_mix", "smoke"])
+@pytest.mark.parametrize("name", ["cornell", "hollow_glass", "default", "light_test", "two_meshes", "texture_mix", "smoke", "cornell_smoke", "nested_volumes"])
 def test_every_kernel_variant_is_bit_identical(dev, name, monkeypatch):
     """The wavefront kernels exist in several template variants (counters on/off, small tables in
     LDS or global memory, split or combined intersect).  hipcc (ROCm 7.2) has produced wrong Dielectric

@@ -249,19 +249,21 @@ def test_struct_sizes_match_the_header(repo_dir, tmp_path):
 
 def test_scene_compiler_rejects_unsupported_without_gpu(tmp_path):
     """rt_scene_create compiles the scene before touching the device, so feature errors are
-    reported on any machine: a volume nested in another volume's boundary is RT_E_UNSUPPORTED (-2),
-    never silently dropped; a plain volume compiles (and then fails at device selection here)."""
+    reported on any machine: volumes nested THREE levels deep in volume boundaries are RT_E_UNSUPPORTED (-2), never
+    silently dropped; a plain volume and a volume inside a volume's boundary (tests/scenes/nested_volumes) compile (and then
+    fail at device selection here)."""
     s = tmp_path / "vol"
     s.write_text("m: isotropic (constant 1,1,1)\nb: sphere 0,0,0 1 (glass)\nv: volume $b $m 0.5\n"
-                 "w: volume $v $m 0.5\nsky: sky (constant 1,1,1)\nworld: list $w $sky\nlights: list $sky\n")
+                 "w: volume $v $m 0.5\nx: volume $w $m 0.5\nsky: sky (constant 1,1,1)\nworld: list $x $sky\nlights: list $sky\n")
     hs = scene(str(s))
     with pytest.raises(api.RtError) as e:
         api.DeviceScene(hs.desc, 0)
     assert e.value.status == api.RT_E_UNSUPPORTED
-    s.write_text("m: isotropic (constant 1,1,1)\nb: sphere 0,0,0 1 (glass)\nv: volume $b $m 0.5\n"
-                 "sky: sky (constant 1,1,1)\nworld: list $v $sky\nlights: list $sky\n")
-    hs = scene(str(s))
-    try:
-        api.DeviceScene(hs.desc, 0)
-    except api.RtError as e2:
-        assert e2.status not in (api.RT_E_UNSUPPORTED, api.RT_E_INVALID), e2
+    for world in ("$v", "$w"):
+        s.write_text("m: isotropic (constant 1,1,1)\nb: sphere 0,0,0 1 (glass)\nv: volume $b $m 0.5\nw: volume $v $m 0.5\n"
+                     f"sky: sky (constant 1,1,1)\nworld: list {world} $sky\nlights: list $sky\n")
+        hs = scene(str(s))
+        try:
+            api.DeviceScene(hs.desc, 0)
+        except api.RtError as e2:
+            assert e2.status not in (api.RT_E_UNSUPPORTED, api.RT_E_INVALID), e2

@@ -197,7 +197,8 @@ def test_lerp_endpoints_and_channel(tmp_path):
 def test_texture_scenes_compile_without_gpu_and_depth_limit(tmp_path):
     """rt_scene_create compiles texture expressions to postfix programs before touching the device:
     the reference's three texture scenes compile (they fail later, at device selection, on a CPU box),
-    an expression that needs more than 4 live values is RT_E_UNSUPPORTED, a type error RT_E_INVALID."""
+    an expression deeper than the interpreter's four register slots compiles too (its stack spills, tests/scenes/deep_texture);
+    only one that needs more than 16 live values is RT_E_UNSUPPORTED; a type error is RT_E_INVALID."""
     for name in ("scenes/perlin", "scenes/earth", "scenes/texture_test", "tests/scenes/texture_mix"):
         hs = api.HostScene([os.path.join(REPO, name)])
         try:
@@ -205,7 +206,15 @@ def test_texture_scenes_compile_without_gpu_and_depth_limit(tmp_path):
         except api.RtError as e:   # no GPU here: anything but a scene error
             assert e.status not in (api.RT_E_UNSUPPORTED, api.RT_E_INVALID), e
     deep = "t: lerp (constant 0,0,0) (constant 1,1,1) (lerp (constant 0) (constant 1) (lerp (constant 0) (constant 1) (constant 0.5)))"
-    hs, _ = texture_scene(tmp_path, deep)
+    hs, _ = texture_scene(tmp_path, deep)   # 7 live values: compiles since round 3
+    try:
+        api.DeviceScene(hs.desc, 0)
+    except api.RtError as e:
+        assert e.status not in (api.RT_E_UNSUPPORTED, api.RT_E_INVALID), e
+    inner = "(constant 0.5)"
+    for _ in range(8):   # 2 live values per level + 1: 17 > 16
+        inner = f"(lerp (constant 0) (constant 1) {inner})"
+    hs, _ = texture_scene(tmp_path, "t: lerp (constant 0,0,0) (constant 1,1,1) " + inner)
     with pytest.raises(api.RtError) as e:
         api.DeviceScene(hs.desc, 0)
     assert e.value.status == api.RT_E_UNSUPPORTED
