@@ -1165,9 +1165,6 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4
 #endif
-#ifndef RT_SHADE_PREFETCH
-#define RT_SHADE_PREFETCH 0  // 1: touch the next trip's triangle attributes one trip ahead (A/B build: -DRT_SHADE_PREFETCH=1)
-#endif
 #define RT_SHADE_BOUNDS __launch_bounds__(256, TEX ? 1 : RT_SHADE_WAVES)
 
 // Diagnostic build (-DRT_SHADE_STAMPS, tools/gpu_shade_stamps.sh): where a wave of k_wf_shade spends its cycles.  s_memtime stamps
@@ -1212,25 +1209,12 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
     unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
 #endif
     // ---- phase 1: one path vertex per lane, chunk by chunk ----
-    uint32_t touched = 0;  // see the prefetch below
     for (uint32_t base = begin; base < end; base += blockDim.x) {
         const uint32_t i = base + threadIdx.x;
         const bool active = i < end;
         bool alive = false;
         uint32_t slot = 0;
         RT_STAMP(0);
-        // Touch the shading attributes of the NEXT trip's mesh hits now: resolve_hit fetches them (128 B per triangle, random)
-        // as the last link of a chain  slot -> hit record -> triangle -> attributes  and nearly every wave holds a mesh hit,
-        // so every trip used to wait for a fetch from HBM.  One dword per 64-B half pulls the line into this XCD's L2 a whole
-        // trip ahead; the values only feed a word that is never stored.
-        if (RT_SHADE_PREFETCH && i + blockDim.x < end) {
-            const uint32_t nslot = full ? i + blockDim.x : queue_in[i + blockDim.x];
-            const int32_t ntri = at(pool.htri, nslot);
-            if (ntri >= 0) {
-                const uint32_t* a = reinterpret_cast<const uint32_t*>(sc.attrs + ntri);
-                touched ^= a[0] ^ a[sizeof(TriAttr<R>) / 8];
-            }
-        }
         if (active) {
             slot = full ? i : queue_in[i];
             PathState<R> ps;
@@ -1332,7 +1316,6 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
     __syncthreads();
     const uint32_t qb = lc[4];
     for (uint32_t j = threadIdx.x; j < n_alive; j += blockDim.x) queue_out[qb + j] = alive_list[j];
-    if (RT_SHADE_PREFETCH && touched == 0x9E3779B9u && n == 0xFFFFFFFFu) lc[7] = touched;  // keeps the touches alive; never true
     RT_STAMP(6);
 #ifdef RT_SHADE_STAMPS
     if ((threadIdx.x & 63u) == 0) {

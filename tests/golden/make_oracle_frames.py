@@ -26,6 +26,14 @@ CASES = {
     "texture_mix": ["tests/scenes/texture_mix", "-w=48", "-s=16", "--seed=15"],
     "smoke": ["tests/scenes/smoke", "-w=48", "-s=16", "--seed=16"],
     "box_light": ["tests/scenes/box_light", "-w=48", "-s=16", "--seed=17"],
+    # round 3: sphere / sky UV maps through det_acos / det_atan2, nested lights / volumes, spilled texture stacks, volumes in k_wf_prims
+    "earth": ["scenes/earth", "-w=48", "-s=16", "--seed=13"],
+    "sun_sky": ["tests/scenes/sun_sky", "-w=48", "-s=16", "--seed=6"],
+    "cornell_smoke": ["scenes/cornell_smoke", "-w=48", "-s=16", "--seed=21"],
+    "nested_volumes": ["tests/scenes/nested_volumes", "-w=48", "-s=16", "--seed=22"],
+    "nested_lights": ["tests/scenes/nested_lights", "-w=48", "-s=16", "--seed=23"],
+    "deep_texture": ["tests/scenes/deep_texture", "-w=48", "-s=16", "--seed=24"],
+    "two_meshes": ["tests/scenes/two_meshes", "-w=48", "-s=16", "--seed=11"],
 }
 
 

@@ -39,6 +39,9 @@ SCENES = {
     # texture interpreter variants of the kernels (image / noise / lerp / channel textures, normal maps)
     "perlin": ["scenes/perlin", "-w=48", "-s=16", "--seed=12"],
     "earth": ["scenes/earth", "-w=48", "-s=16", "--seed=13"],          # JPEG texture on a sphere
+    # the same at 320 x 180: one nearest-neighbour texel of the 2048-px map per ~0.4 pixel, so most samples sit next to a texel edge:
+    # u = (atan2 + pi) / 2 pi and v = acos / pi must be the oracle's bits (include/rt_detmath.h det_atan2 / det_acos on both sides)
+    "earth_dense": ["scenes/earth", "-w=320", "-s=4", "--seed=25"],
     "texture_test": ["scenes/texture_test", "-w=48", "-s=16", "--seed=14"],  # PNG albedo / roughness channel / normal map on a mesh
     "texture_mix": ["tests/scenes/texture_mix", "-w=48", "-s=16", "--seed=15"],  # every operator, every primitive's tangent frame
     # constant-density volumes (sphere / mesh / box boundaries); wavefront: combined intersect kernel, VOL variant (a mesh in a boundary)
