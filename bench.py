@@ -100,19 +100,24 @@ def cpu_model() -> str:
 
 
 def physical_cores():
-    """One hardware thread per physical core of the CPUs this process may run on (SMT siblings dropped)."""
+    """One hardware thread per physical core of the CPUs this process may run on (SMT siblings dropped), grouped by socket:
+    returns the cores of the socket that offers most of them (the oracle's scene then lives in that socket's memory: the
+    process is pinned there BEFORE the scene is loaded, first touch)."""
     allowed = sorted(os.sched_getaffinity(0))
-    seen, cores = set(), []
+    seen, by_pkg = set(), {}
     for cpu in allowed:
+        base = f"/sys/devices/system/cpu/cpu{cpu}/topology/"
         try:
-            with open(f"/sys/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list") as f:
-                key = f.read().strip()
+            with open(base + "thread_siblings_list") as f:
+                sib = f.read().strip()
+            with open(base + "physical_package_id") as f:
+                pkg = f.read().strip()
         except OSError:
-            key = str(cpu)
-        if key not in seen:
-            seen.add(key)
-            cores.append(cpu)
-    return cores
+            sib, pkg = str(cpu), "0"
+        if (pkg, sib) not in seen:
+            seen.add((pkg, sib))
+            by_pkg.setdefault(pkg, []).append(cpu)
+    return max(by_pkg.values(), key=len)
 
 
 def _oracle_rows(hs, p, stride):
@@ -146,9 +151,19 @@ def cpu_baseline(workload: str, seed: int):
     from rust_raytracer_amd import api
 
     args, _ = WORKLOADS[workload]
+    avail = len(os.sched_getaffinity(0))
+    saved_affinity = os.sched_getaffinity(0)
+    cores = physical_cores()
+    os.sched_setaffinity(0, set(cores))  # one socket, one hardware thread per core; the scene is loaded (first touch) under it
+    try:
+        return _cpu_baseline_pinned(api, args, seed, avail, cores)
+    finally:
+        os.sched_setaffinity(0, saved_affinity)
+
+
+def _cpu_baseline_pinned(api, args, seed, avail, cores):
     hs = api.HostScene(args + [f"--seed={seed}"])
     p = hs.params.copy()
-    avail = len(os.sched_getaffinity(0))
     threads = p.thread_count  # one OS thread per replica (camera.rs:197-241)
     target_samples = 1.3e6 * min(threads, avail) * 0.9  # ~25 s at the oracle's speed on this class of host
     per_row = hs.width * p.sqrt_spt * p.sqrt_spt * threads
@@ -174,8 +189,8 @@ def cpu_baseline(workload: str, seed: int):
         "node_tests_per_ray": tot["nodes"] / max(tot["rays"], 1),
         "tri_tests_per_ray": tot["tris"] / max(tot["rays"], 1),
     }
+    out["pinned_to"] = f"{len(cores)} physical cores of one socket (one hardware thread each)"
     # the same spp on more replicas: T' = the largest T' <= physical cores with T' * floor(sqrt(s / T'))^2 == spp
-    cores = physical_cores()
     spp = threads * p.sqrt_spt * p.sqrt_spt
     best = None
     for t2 in range(min(len(cores), 128), threads, -1):
@@ -187,17 +202,12 @@ def cpu_baseline(workload: str, seed: int):
         t2, s2 = best
         q = p.copy()
         q.thread_count, q.sqrt_spt = t2, s2
-        saved = os.sched_getaffinity(0)
-        try:
-            os.sched_setaffinity(0, set(cores))
-            halves2, tot2 = _oracle_rows(hs, q, stride)
-        finally:
-            os.sched_setaffinity(0, saved)
+        halves2, tot2 = _oracle_rows(hs, q, stride)
         v2 = tot2["samples"] / tot2["seconds"] / 1e6
         out["all_cores"] = {
             "value": v2, "unit": "Msamples/s", "cores": t2, "physical_cores_available": len(cores),
-            "sample": f"the same {rows} rows at the same spp as -t={t2} x {s2}x{s2} strata ({t2} OS threads on {len(cores)} physical cores, one "
-                      f"hardware thread per core): {tot2['samples']} samples in {tot2['seconds']:.1f}s; halves {halves2[0]:.3f} / {halves2[1]:.3f}",
+            "sample": f"the same {rows} rows at the same spp as -t={t2} x {s2}x{s2} strata ({t2} OS threads on the {len(cores)} physical cores of one "
+                      f"socket, one hardware thread per core): {tot2['samples']} samples in {tot2['seconds']:.1f}s; halves {halves2[0]:.3f} / {halves2[1]:.3f}",
             "halves": halves2,
         }
     return out
