@@ -280,6 +280,13 @@ int rt_scene_info(const RtSceneDesc* desc, uint32_t* flags_out);
  * out[0] triangle records, out[1] BVH2 nodes, out[2] 4-wide nodes, out[3] BVH2 depth, out[4] worst-case 4-wide traversal stack,
  * out[5] scene-program ops, out[6] sphere / quad groups re-built as SAH trees, out[7] primitives in them. */
 int rt_scene_mesh_stats(const RtSceneDesc* desc, uint64_t out[8]);
+/* Same, plus the compiled scene program itself (tests of the scene compiler without a GPU): ops_out[4 * i ..] = type, arg,
+ * skip, chain of op i (rt_scene.h OpType; up to `capacity` ops are written, *n_ops_out = the program's length; ops_out may be
+ * NULL).  info[0] mesh ops, [1] primitive groups with a 4-wide BVH, [2] their nodes, [3] their worst-case stack, [4] entries of
+ * the light table (nested lists flattened to a tree), [5] volumes, [6] the wavefront scheduler's kernel plan: bit 0 split
+ * intersect (k_wf_prims + k_wf_mesh), bit 1 volumes inside k_wf_prims, bit 2 multi-mesh form of k_wf_mesh, bit 3 group
+ * BVHs in k_wf_prims; [7] primitives in group BVHs. */
+int rt_scene_program(const RtSceneDesc* desc, int32_t* ops_out, uint32_t capacity, uint32_t* n_ops_out, uint64_t info[8]);
 
 /* Frame pipelining (no counterpart in the reference, which renders one image per process run): while `flag` is set
  * (non-NULL), every rt_render / rt_render_device of this scene object stores 1 to `*flag` as soon as the render can no

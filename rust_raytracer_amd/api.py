@@ -250,6 +250,27 @@ def scene_mesh_stats(desc) -> dict:
                     [int(x) for x in out]))
 
 
+def scene_program(desc) -> tuple:
+    """rt_scene_program: (ops as an (n, 4) int32 array of type / arg / skip / chain, info dict); host only."""
+    import numpy as np
+    lib = load_device_lib()
+    lib.rt_scene_program.argtypes = [C.POINTER(RtSceneDesc), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    lib.rt_scene_program.restype = C.c_int
+    n = C.c_uint32()
+    info = (C.c_uint64 * 8)()
+    st = lib.rt_scene_program(desc, None, 0, C.byref(n), info)
+    if st != RT_OK:
+        raise RtError(st, lib.rt_last_error().decode())
+    ops = np.zeros((n.value, 4), dtype=np.int32)
+    st = lib.rt_scene_program(desc, ops.ctypes.data_as(C.POINTER(C.c_int32)), n.value, C.byref(n), info)
+    if st != RT_OK:
+        raise RtError(st, lib.rt_last_error().decode())
+    plan = int(info[6])
+    return ops, {"mesh_ops": int(info[0]), "groups": int(info[1]), "group_nodes": int(info[2]), "group_stack": int(info[3]),
+                 "lights": int(info[4]), "volumes": int(info[5]), "group_prims": int(info[7]),
+                 "split": bool(plan & 1), "vol_prims": bool(plan & 2), "multi_mesh": bool(plan & 4), "group_bvh": bool(plan & 8)}
+
+
 def owned_rows(height: int, params: RtRenderParams) -> list:
     """Rows of the frame that the partition in `params` assigns to this part (rt_owned_rows)."""
     if params.band_rows == 0 or params.n_parts <= 1:

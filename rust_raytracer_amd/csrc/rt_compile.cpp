@@ -934,6 +934,29 @@ struct Compiler {
 
 }  // namespace
 
+// The split intersect: k_wf_prims for the spheres / quads / sky / sun (and the volumes they bound) and, when the program has
+// mesh ops (any number of instances), k_wf_mesh for those.  Scenes it does not cover use the combined kernel
+// (k_wf_intersect): a mesh inside a volume's boundary, or in front of a volume in program order (the volume's free-flight
+// draw depends on the closest hit so far, volume.rs:40-43, so that mesh cannot be deferred); more than 32 766 mesh ops
+// (k_wf_mesh packs the mesh-op index in 15 bits).  Groups: their nodes (<= 24 KB) and a per-lane stack (<= 16 levels) must
+// fit k_wf_prims' LDS; volumes and groups do not combine (k_wf_prims<VOL> walks the op form).
+WavefrontPlan plan_wavefront(const CompiledScene& cs) {
+    WavefrontPlan p{};
+    const bool vol = !cs.volumes.empty();
+    bool vol_ok = true;
+    if (vol) {
+        int32_t last_vol = -1;
+        for (size_t i = 0; i < cs.ops.size(); i++)
+            if (cs.ops[i].type == OP_VOL_END) last_vol = int32_t(i);
+        vol_ok = cs.mesh_ops.empty() || cs.mesh_ops.front() > last_vol;
+    }
+    p.split = vol_ok && cs.mesh_ops.size() < 32767;
+    p.vol_prims = p.split && vol;
+    p.multi_mesh = cs.mesh_ops.size() > 1;
+    p.groups = p.split && !vol && !cs.group_nodes4.empty() && cs.max_group_stack <= 16 && cs.group_nodes4.size() * 64 <= 24u * 1024u;
+    return p;
+}
+
 int compile_scene(const RtSceneDesc* desc, CompiledScene* out, std::string* err, const CompileOptions& opt) {
     if (!desc || desc->abi_version != RT_MI355_ABI_VERSION) {
         *err = "scene description missing or ABI version mismatch";

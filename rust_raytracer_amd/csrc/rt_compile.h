@@ -58,6 +58,16 @@ struct CompileOptions {
     bool rebuild_prim_groups = true;  // re-build sphere / quad subtrees of >= 12 primitives (RT_PRIM_REBUILD=0 keeps the reference's tree)
 };
 
+// Which kernels the wavefront scheduler runs for a compiled scene (rt_kernels.hip render_wavefront; also reported by
+// rt_scene_program so that the choice is testable without a GPU).
+struct WavefrontPlan {
+    bool split;        // k_wf_prims (+ k_wf_mesh when the program has mesh ops) instead of the combined k_wf_intersect
+    bool vol_prims;    // ... with the volumes inside k_wf_prims<VOL>
+    bool multi_mesh;   // k_wf_mesh<MULTI>: more than one mesh op
+    bool groups;       // k_wf_prims<GROUPS>: re-built primitive groups searched through their 4-wide BVH
+};
+WavefrontPlan plan_wavefront(const CompiledScene& cs);
+
 // Returns RT_OK or a negative RtStatus with `err` set.
 int compile_scene(const RtSceneDesc* desc, CompiledScene* out, std::string* err, const CompileOptions& opt = CompileOptions());
 

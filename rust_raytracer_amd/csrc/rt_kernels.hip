@@ -780,23 +780,13 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     if (vol) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_intersect<R, false, true>, 256, lds));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_wf_intersect<R, false, false>, 256, lds));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
-    // The split intersect: k_wf_prims for the spheres / quads / sky / sun (and the volumes they bound) and, when the program has
-    // mesh ops (any number of instances), k_wf_mesh for those.  Scenes it does not cover use the combined kernel
-    // (k_wf_intersect): a mesh inside a volume's boundary, or in front of a volume in program order (the volume's free-flight
-    // draw depends on the closest hit so far, volume.rs:40-43, so that mesh cannot be deferred).  RT_WF_SPLIT=0 (tests):
-    // the combined kernel for every scene.
+    // which kernels serve this scene (rt_compile.cpp plan_wavefront); RT_WF_SPLIT=0 (tests): the combined kernel for every scene
+    const WavefrontPlan plan = plan_wavefront(s->compiled);
     const int n_mesh_ops = int(s->compiled.mesh_ops.size());
-    bool vol_split_ok = true;
-    if (vol) {
-        int32_t last_vol = -1;
-        for (size_t i = 0; i < s->compiled.ops.size(); i++)
-            if (s->compiled.ops[i].type == OP_VOL_END) last_vol = int32_t(i);
-        vol_split_ok = n_mesh_ops == 0 || s->compiled.mesh_ops.front() > last_vol;
-    }
-    const bool use_split = env_u32("RT_WF_SPLIT", 1) != 0 && vol_split_ok && n_mesh_ops < 32767;  // k_wf_mesh packs the mesh-op index in 15 bits
+    const bool use_split = env_u32("RT_WF_SPLIT", 1) != 0 && plan.split;
     const bool prims_only = use_split && n_mesh_ops == 0;
     const bool split = use_split && n_mesh_ops > 0;
-    const bool multi_mesh = n_mesh_ops > 1 || env_u32("RT_WF_MESH_MULTI", 0) != 0;  // the general form of k_wf_mesh (env: A/B on single-mesh scenes, tests)
+    const bool multi_mesh = plan.multi_mesh || env_u32("RT_WF_MESH_MULTI", 0) != 0;  // the general form of k_wf_mesh (env: A/B on single-mesh scenes, tests)
     // k_wf_mesh keeps (child, entry distance) pairs: a shallow LDS part (occupancy) + a global spill part
     // BVH node format of k_wf_mesh: 1 = 4-wide quantised (BvhNode4q, 64 B, default), 0 = 4-wide f32 (BvhNode4f, 128 B; A/B control).
     // An 8-wide quantised node (a third fewer visits) was slower: profiles/r02/ab/node_width_and_size.txt.
@@ -848,8 +838,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     // groups need more than that LDS (> 24 KB of nodes, > 16 stack levels) keep the op form.  RT_WF_GROUPS=0: A/B, tests.
     const uint32_t group_levels = uint32_t(ds.view.group_stack_levels);
     const size_t group_node_bytes = size_t(ds.view.n_group_nodes) * sizeof(BvhNode4q);
-    const bool groups = (split || prims_only) && !vol && ds.view.n_group_nodes > 0 && group_levels <= 16 && group_node_bytes <= 24u * 1024u &&
-                        env_u32("RT_WF_GROUPS", 1) != 0;
+    const bool groups = (split || prims_only) && plan.groups && env_u32("RT_WF_GROUPS", 1) != 0;
     const size_t lds_groups = groups ? size_t(group_levels) * 256 * 8 + group_node_bytes : 0;
     uint32_t staged_prims = staged_prefix(ds.view.lay);
     const uint32_t staged_shade = staged_prefix(ds.view.lay_shade);
@@ -1273,6 +1262,33 @@ int rt_scene_mesh_stats(const RtSceneDesc* desc, uint64_t out[8]) {
     out[5] = cs.ops.size();
     out[6] = cs.n_rebuilt_groups;
     out[7] = cs.n_rebuilt_prims;
+    return RT_OK;
+}
+
+int rt_scene_program(const RtSceneDesc* desc, int32_t* ops_out, uint32_t capacity, uint32_t* n_ops_out, uint64_t info[8]) {
+    using namespace rt;
+    if (!desc || !n_ops_out || !info) return set_err(RT_E_INVALID, "rt_scene_program: NULL argument");
+    CompiledScene cs;
+    std::string err;
+    CompileOptions opt;
+    if (const char* e = std::getenv("RT_PRIM_REBUILD")) opt.rebuild_prim_groups = std::atoi(e) != 0;
+    int st = compile_scene(desc, &cs, &err, opt);
+    if (st != RT_OK) return set_err(st, err);
+    *n_ops_out = uint32_t(cs.ops.size());
+    if (ops_out)
+        for (size_t i = 0; i < cs.ops.size() && i < capacity; i++) {
+            ops_out[4 * i + 0] = cs.ops[i].type; ops_out[4 * i + 1] = cs.ops[i].arg;
+            ops_out[4 * i + 2] = cs.ops[i].skip; ops_out[4 * i + 3] = cs.ops[i].chain;
+        }
+    const WavefrontPlan plan = plan_wavefront(cs);
+    info[0] = cs.mesh_ops.size();
+    info[1] = cs.groups.size();
+    info[2] = cs.group_nodes4.size();
+    info[3] = cs.max_group_stack;
+    info[4] = cs.lights.size();
+    info[5] = cs.volumes.size();
+    info[6] = (plan.split ? 1u : 0u) | (plan.vol_prims ? 2u : 0u) | (plan.multi_mesh ? 4u : 0u) | (plan.groups ? 8u : 0u);
+    info[7] = cs.group_prims.size();
     return RT_OK;
 }
 
