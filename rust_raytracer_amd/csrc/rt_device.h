@@ -85,7 +85,14 @@ template <typename R> RT_DEV void onb_from_vec(V3<R> w, V3<R>& u, V3<R>& v) {
     v = to_unit(cross(w, a));
     u = cross(w, v);
 }
-// utils.rs:31-36 (powi(5) = x2 = x*x; x4 = x2*x2; x4*x)
+// utils.rs:31-36 (powi(5) = x2 = x*x; x4 = x2*x2; x4*x) with r0 = ((1 - ior_ratio) / (1 + ior_ratio))^2 taken from the
+// material's constants (MaterialParams: the same operations, done once on the host)
+template <typename R> RT_DEV R reflectance_r0(R cos_theta, R r0) {
+    R x = R(1) - cos_theta;
+    R x2 = x * x;
+    R x4 = x2 * x2;
+    return r0 + (R(1) - r0) * (x4 * x);
+}
 template <typename R> RT_DEV R reflectance(R cos_theta, R ior_ratio) {
     R r0 = (R(1) - ior_ratio) / (R(1) + ior_ratio);
     r0 = r0 * r0;
@@ -921,7 +928,7 @@ template <typename R, bool STATS> RT_DEV R light_pdf_value(const SceneView<R>& s
 template <typename R, bool STATS, bool FULL> RT_DEV R lights_pdf_value(const SceneView<R>& sc, V3<R> origin, V3<R> dir, LaneCounters& cnt) {
     if (!sc.lights_is_list) return light_pdf_value<R, STATS>(sc, sc.lights[0], origin, dir, cnt);
     if constexpr (!FULL) {
-        R weight = R(1) / R(sc.n_lights);
+        const R weight = sc.inv_n_lights;
         R sum = R(0);
         for (int32_t i = 0; i < sc.n_lights; i++) sum += weight * light_pdf_value<R, STATS>(sc, sc.lights[i], origin, dir, cnt);
         return sum;
@@ -929,7 +936,7 @@ template <typename R, bool STATS, bool FULL> RT_DEV R lights_pdf_value(const Sce
         int32_t first[kMaxLightDepth], count[kMaxLightDepth], next[kMaxLightDepth];
         R sum[kMaxLightDepth], weight[kMaxLightDepth];
         int depth = 0;
-        first[0] = 0; count[0] = sc.n_lights; next[0] = 0; sum[0] = R(0); weight[0] = R(1) / R(sc.n_lights);
+        first[0] = 0; count[0] = sc.n_lights; next[0] = 0; sum[0] = R(0); weight[0] = sc.inv_n_lights;
         for (;;) {
             if (next[depth] == count[depth]) {  // this list is summed up: hand the value to its parent
                 if (depth == 0) return sum[0];
@@ -1128,13 +1135,13 @@ RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathStat
             break;
         }
         case RT_MAT_DIELECTRIC: {  // dielectric.rs:29-54, attenuation (1,1,1)
-            R ior = sc.material_params[hit.material].ior;
-            R ior_ratio = hit.front_face ? R(1) / ior : ior;
+            const MaterialParams<R>& mp = sc.material_params[hit.material];
+            R ior_ratio = hit.front_face ? mp.inv_ior_r : mp.ior;  // dielectric.rs:31
             V3<R> unit_dir = to_unit(ps.ray.d);
             R cos_theta = fmin(R(1), dot(-unit_dir, hit.normal));
             R sin_theta = sqrt(R(1) - cos_theta * cos_theta);
             bool tir = ior_ratio * sin_theta > R(1);
-            bool reflected = tir || reflectance(cos_theta, ior_ratio) > rng_uniform<R>(rng);  // no draw on TIR
+            bool reflected = tir || reflectance_r0(cos_theta, hit.front_face ? mp.r0_front : mp.r0_back) > rng_uniform<R>(rng);  // no draw on TIR
             dir = reflected ? reflect(unit_dir, hit.normal) : refract(unit_dir, hit.normal, ior_ratio);
             break;
         }
@@ -1142,7 +1149,7 @@ RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathStat
             V3<R> normal = hit.normal;
             V3<R> unit_dir = to_unit(ps.ray.d);
             R cos_theta = fmin(R(1), dot(-unit_dir, normal));
-            bool specular = reflectance(cos_theta, sc.material_params[hit.material].inv_ior) > rng_uniform<R>(rng);
+            bool specular = reflectance_r0(cos_theta, sc.material_params[hit.material].r0_glossy) > rng_uniform<R>(rng);
             if (specular) {  // attenuation (1,1,1)
                 R roughness = hit.tex_b;
                 V3<R> reflected = reflect(ps.ray.d, normal);
@@ -1177,9 +1184,12 @@ RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathStat
             scattering_pdf = R(1) / (R(4) * pi<R>());  // isotropic.rs:35-37
         } else {
             V3<R> unit = to_unit(dir);
-            first_val = fmax(dot(unit, pdf_w) / pi<R>(), R(0));  // cosine.rs:26-29
-            R cos_theta = dot(pdf_w, unit);                      // lambertian.rs:35-43 / glossy.rs:86-95
-            scattering_pdf = cos_theta < R(0) ? R(0) : cos_theta / pi<R>();
+            // cosine.rs:26-29 takes dot(unit, w) / pi, lambertian.rs:35-43 / glossy.rs:86-95 dot(w, unit) / pi: the products commute
+            // and the sums run over x, y, z in both, so it is ONE value and one division
+            const R cos_theta = dot(pdf_w, unit);
+            const R cos_over_pi = cos_theta / pi<R>();
+            first_val = fmax(cos_over_pi, R(0));
+            scattering_pdf = cos_theta < R(0) ? R(0) : cos_over_pi;
         }
         R second_val = lights_pdf_value<R, STATS, FULL>(sc, hit.pos, dir, cnt);
         R pdf = first_val * (R(1) - prm.light_bias) + second_val * prm.light_bias;

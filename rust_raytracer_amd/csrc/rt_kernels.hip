@@ -416,6 +416,11 @@ struct DeviceScene {
         for (size_t i = 0; i < mparams.size(); i++) {
             mparams[i].ior = R(cs.material_params[i].ior);
             mparams[i].inv_ior = R(cs.material_params[i].inv_ior);
+            auto r0_of = [](R x) { R r0 = (R(1) - x) / (R(1) + x); return r0 * r0; };  // utils.rs:32-33, in R like reflectance()
+            mparams[i].inv_ior_r = R(1) / mparams[i].ior;
+            mparams[i].r0_glossy = r0_of(mparams[i].inv_ior);
+            mparams[i].r0_front = r0_of(mparams[i].inv_ior_r);
+            mparams[i].r0_back = r0_of(mparams[i].ior);
         }
         std::vector<TextureRec<R>> textures(cs.textures.size());
         for (size_t i = 0; i < textures.size(); i++) {
@@ -516,6 +521,7 @@ struct DeviceScene {
             if ((st = pack(order_shade, view.lay_shade, &view.small_blob_shade)) != RT_OK) return st;
         }
         view.n_lights = cs.n_top_lights;
+        view.inv_n_lights = R(1) / R(cs.n_top_lights);
         view.lights_is_list = cs.lights_is_list;
         view.stop_on_zero_weight = cs.zero_weight_stop ? 1 : 0;
         if (const char* e = std::getenv("RT_ZERO_WEIGHT_STOP")) view.stop_on_zero_weight = std::atoi(e) != 0;  // experiments

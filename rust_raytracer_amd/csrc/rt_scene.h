@@ -188,6 +188,13 @@ template <typename R>
 struct MaterialParams {
     R ior;      // Dielectric::ior
     R inv_ior;  // Glossy::inv_ior = 1 / ior (glossy.rs:30), computed in f64 then rounded
+    // Per-material constants of the Schlick term (utils.rs:31-36: r0 = ((1 - x) / (1 + x))^2 for x = the ior ratio), computed once
+    // on the host in R with the kernels' own operation order - the same IEEE operations on the same operands, so the same bits
+    // as evaluating them at every vertex (one f64 division less per Glossy vertex, two per Dielectric vertex):
+    R inv_ior_r;     // R(1) / ior in R arithmetic: the front-face ratio of Dielectric (dielectric.rs:31)
+    R r0_glossy;     // x = inv_ior
+    R r0_front;      // x = inv_ior_r
+    R r0_back;       // x = ior
 };
 
 // Texture expressions are compiled to POSTFIX programs (rt_compile.cpp): a material slot holds
@@ -274,6 +281,7 @@ struct SceneView {
     const uint32_t* perlin_perm;     // per generator: perm_x, perm_y, perm_z (3 x 256)
     const LightRec* lights;
     int32_t n_lights;
+    R inv_n_lights;          // R(1) / R(n_lights): the weight of list.rs:81, computed once on the host in R
     int32_t lights_is_list;  // lights root is an ObjectList (list.rs:80-100) vs a single object
     int32_t stop_on_zero_weight;  // CompiledScene::zero_weight_stop: a path whose throughput is exactly 0 may end (rt_device.h, path_goes_on)
     int32_t stack_entries;   // per-lane LDS traversal stack size
