@@ -1158,14 +1158,19 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
 // ---------------------------------------------------------------------------------------------
 // Shade: one path vertex per lane (camera.rs:295-331), regeneration in place and queue compaction.
 // ---------------------------------------------------------------------------------------------
-// Waves per SIMD asked of the register allocator for k_wf_shade: 4 (<= 128 VGPRs) for the lean variant.  It needs 106 since
-// the inverse trigonometric functions of the UV maps are called out of line (uv_acos / uv_atan2 in rt_device.h: inlined, their
-// polynomial coefficients sat in 50 VGPRs for the whole kernel); 166 and 3 waves before that, 188-197 and 2 waves in round 1.
-// 5 waves (96 VGPRs + 16 B of scratch) are slower.  The texture-interpreter variants need 174-189: no cap for them.
+// Waves per SIMD asked of the register allocator for k_wf_shade.  The lean variant with every small table in LDS (LDS == 1:
+// the headline scenes) fits 95 VGPRs without scratch since round 3 (sample-index split by reciprocals, Schlick constants from
+// the host) and runs at 5 waves: -4.5 % (C4) to -7.5 % (default scene) of the kernel's time against 4 waves
+// (profiles/r03/ab/shade_five_waves.txt).  It fits with NOTHING to spare: tools/kernel_regs.py after every change to the
+// shading code - at 96 VGPRs + 32 B of scratch the gain is gone.  The variants that read the tables from global memory and the
+// counting variants need 16-48 B of scratch at that size and stay at 4 (<= 128 VGPRs).  History: 106 VGPRs since the inverse
+// trigonometric functions of the UV maps are called out of line (uv_acos / uv_atan2 in rt_device.h: inlined, their polynomial
+// coefficients sat in 50 VGPRs for the whole kernel); 166 and 3 waves before that, 188-197 and 2 waves in round 1.  The
+// texture-interpreter variants need 174-189: no cap.
 #ifndef RT_SHADE_WAVES
-#define RT_SHADE_WAVES 4
+#define RT_SHADE_WAVES 5
 #endif
-#define RT_SHADE_BOUNDS __launch_bounds__(256, TEX ? 1 : RT_SHADE_WAVES)
+#define RT_SHADE_BOUNDS __launch_bounds__(256, TEX ? 1 : (LDS == 1 && !STATS ? RT_SHADE_WAVES : 4))
 
 // Diagnostic build (-DRT_SHADE_STAMPS, tools/gpu_shade_stamps.sh): where a wave of k_wf_shade spends its cycles.  s_memtime stamps
 // around the sections of a trip, summed per wave and added to g_shade_stamps at the end; never compiled into the product.
