@@ -49,6 +49,11 @@ WORKLOADS = {
               "scenes/cornell_dragon 1200x1200 @1000spp with the stand-in mesh at 1320x1320 quads = 3484800 triangles"),
     "c4_14m": (["build/bigmesh/cornell_dragon_14m", "-w=1200", "-s=1000", "-t=10"],
                "scenes/cornell_dragon 1200x1200 @1000spp with the stand-in mesh at 2640x2640 quads = 13939200 triangles"),
+    # the other direction (does k_wf_mesh get faster when its working set fits the L2s?): 330 / 165 quads per side
+    "c4_218k": (["build/bigmesh/cornell_dragon_218k", "-w=1200", "-s=1000", "-t=10"],
+                "scenes/cornell_dragon 1200x1200 @1000spp with the stand-in mesh at 330x330 quads = 217800 triangles"),
+    "c4_54k": (["build/bigmesh/cornell_dragon_54k", "-w=1200", "-s=1000", "-t=10"],
+               "scenes/cornell_dragon 1200x1200 @1000spp with the stand-in mesh at 165x165 quads = 54450 triangles"),
     "two_meshes": (["tests/scenes/two_meshes", "-w=800", "-s=256"], "tests/scenes/two_meshes 800x800 @256spp, two transformed mesh instances (2 x 967 tri)"),
     "smoke": (["scenes/cornell_smoke", "-w=800", "-s=256"], "scenes/cornell_smoke 800x800 @256spp, two constant-density volumes bounded by boxes"),
 }
@@ -65,7 +70,7 @@ def ensure_dragon():
         os.replace(tmp, path)
 
 
-BIG_MESHES = {"c4_3m": ("3m", 1320), "c4_14m": ("14m", 2640)}
+BIG_MESHES = {"c4_3m": ("3m", 1320), "c4_14m": ("14m", 2640), "c4_218k": ("218k", 330), "c4_54k": ("54k", 165)}
 
 
 def ensure_big_dragon(workload: str):
