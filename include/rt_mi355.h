@@ -268,6 +268,12 @@ int rt_debug_trace_sample(const RtScene* scene, const RtCameraDesc* camera, cons
                           uint32_t tid, uint32_t x, uint32_t y, uint32_t sx, uint32_t sy,
                           double* rgb_out, double* trace_out, uint32_t max_bounces);
 
+/* Diagnostic probe (tests): the specular reflection of Metal / Glossy (metal.rs:33-35, glossy.rs:66-68) as the kernels compute
+ * it - with the shortcut for a fuzz / roughness of exactly 0 - next to the plain expression, on `n` inputs (reflected[3 n],
+ * fuzz[n], generator state[n]): out[6 i ..] = the kernels' direction, then the plain one; state_out[2 i ..] = the generator
+ * after each.  The two must agree bit for bit. */
+int rt_debug_fuzzy_reflection(int device, uint32_t n, const double* reflected, const double* fuzz, const uint64_t* state, double* out, uint64_t* state_out);
+
 /* Diagnostic (host only, needs no device): compiles `desc` like rt_scene_create and reports how the scene
  * compiler classified it.  RT_SCENE_INFO_ZERO_WEIGHT_STOP: the light set cannot give an infinite or NaN weight,
  * so paths whose weight is exactly 0 are ended early (otherwise they are traced to the end like

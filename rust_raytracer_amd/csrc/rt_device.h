@@ -147,6 +147,27 @@ template <typename R> RT_DEV V3<R> random_unit(Rng& g) {  // vec4.rs:42-48
     R z = rng_normal<R>(g);
     return to_unit(mk<R>(x, y, z));
 }
+// reflected + random_unit(rng) * fuzz * length(reflected)  (metal.rs:33-35, glossy.rs:66-68).  For fuzz == 0 - a polished
+// metal, the clear coat of `glossy (..) (constant 0)` in the reference's own scenes - the random term is (n * 0) * len = +-0
+// per component: n is a unit vector of three finite normal samples, so with a finite length the sum is `reflected` itself bit
+// for bit unless a component of `reflected` is a zero (-0 + +0 = +0).  Then the three Box-Muller samples (3 x ln, sqrt,
+// sin / cos: ~800 f64 instructions that a wave executes for ALL its lanes as soon as one lane reflects specularly) are not
+// computed; the generator still moves on by their six draws (SplitMix64: six increments).  Not covered: all three normal
+// samples exactly zero (u1 = 0 three times in a row, 2^-159), where the reference normalises a zero vector and gets NaN.
+template <typename R> RT_DEV V3<R> fuzzy_reflection(V3<R> reflected, R fuzz, Rng& g) {
+    const R lim = sizeof(R) == 8 ? R(1e150) : R(1e18);  // below it length_squared cannot overflow
+    const bool plain = fuzz == R(0) && reflected.x != R(0) && reflected.y != R(0) && reflected.z != R(0) &&
+                       fabs(reflected.x) < lim && fabs(reflected.y) < lim && fabs(reflected.z) < lim;
+#ifdef RT_WHATIF_NO_FUZZ  // timing experiment only (wrong frames): what would k_wf_shade cost if NO vertex computed the three normal samples?
+    if (true) {
+#else
+    if (plain) {
+#endif
+        g.s += 6ull * 0x9E3779B97F4A7C15ull;
+        return reflected;
+    }
+    return reflected + random_unit<R>(g) * fuzz * length(reflected);
+}
 template <typename R> RT_DEV V3<R> random_cosine(Rng& g) {  // vec4.rs:50-61
     R r1 = rng_uniform<R>(g);
     R r2 = rng_uniform<R>(g);
@@ -1128,7 +1149,7 @@ RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathStat
             break;
         case RT_MAT_METAL: {  // metal.rs:28-44
             V3<R> reflected = reflect(ps.ray.d, hit.normal);
-            dir = reflected + random_unit<R>(rng) * hit.tex_b * length(reflected);
+            dir = fuzzy_reflection(reflected, hit.tex_b, rng);
             if (!(dot(dir, hit.normal) > R(0))) { end_black(ps); return false; }  // Absorbed (camera.rs:326)
             ps.throughput = ps.throughput * hit.tex_a;
             weight_changed = true;
@@ -1153,7 +1174,7 @@ RT_DEV bool shade_hit(const SceneView<R>& sc, const ParamsView<R>& prm, PathStat
             if (specular) {  // attenuation (1,1,1)
                 R roughness = hit.tex_b;
                 V3<R> reflected = reflect(ps.ray.d, normal);
-                dir = reflected + random_unit<R>(rng) * roughness * length(reflected);
+                dir = fuzzy_reflection(reflected, roughness, rng);
                 if (!(dot(dir, normal) > R(0))) { end_black(ps); return false; }  // Absorbed
                 break;
             }

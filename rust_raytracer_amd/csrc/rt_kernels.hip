@@ -850,8 +850,10 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     const uint32_t staged_shade = staged_prefix(ds.view.lay_shade);
     if (groups && lds_groups + staged_prims > 44u * 1024u) staged_prims = 0;  // three workgroups per CU with the group data: tables from global memory
     const int lds_prims = staged_prims == 0 ? 0 : (staged_prims == ds.view.lay.total_bytes ? 1 : 2);          // kernel variant: none / all / prefix
-    // k_wf_shade: all or nothing (a staged prefix read through flat instructions was 3 % slower than global memory on the default scene)
-    const int lds_shade = (staged_shade != 0 && staged_shade == ds.view.lay_shade.total_bytes) ? 1 : (env_u32("RT_LDS_SHADE_PREFIX", 0) && staged_shade ? 2 : 0);
+    // k_wf_shade: all or nothing (a staged prefix read through flat instructions was 3 % slower than global memory on the default scene),
+    // and only while five workgroups still fit a CU's 160 KB next to its lists (<= 23 KB of tables; RT_LDS_SHADE_MAX overrides)
+    const uint32_t shade_tables_max = env_u32("RT_LDS_SHADE_MAX", 32u * 1024u - kShadeListBytes);
+    const int lds_shade = (staged_shade != 0 && staged_shade == ds.view.lay_shade.total_bytes && staged_shade <= shade_tables_max) ? 1 : (env_u32("RT_LDS_SHADE_PREFIX", 0) && staged_shade ? 2 : 0);
     const bool iter_log = env_u32("RT_WF_ITER_LOG", 0) != 0;
     const bool trace_pool = env_u32("RT_WF_TRACE", 0) != 0;  // debug: dump the first pool slots after every iteration
     const uint32_t check_every = trace_pool ? 1u : std::min<uint32_t>(32u, std::max<uint32_t>(1u, env_u32("RT_WF_CHECK", 8)));  // 4 timing events per iteration, 128 events
@@ -923,7 +925,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
 #undef RT_LAUNCH_ISECT
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 }
-#define RT_LAUNCH_SHADE(ST, L, TX) hipLaunchKernelGGL((k_wf_shade<R, ST, L, TX>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), (L ? size_t(staged_shade) : size_t(0)) + (2 * WF_CHUNK + 8) * 4 + shade_lds_pad, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters, static_cast<const WfPool<R>*>(w.pool_dev), staged_shade)
+#define RT_LAUNCH_SHADE(ST, L, TX) hipLaunchKernelGGL((k_wf_shade<R, ST, L, TX>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), (L ? size_t(staged_shade) : size_t(0)) + kShadeListBytes + shade_lds_pad, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters, static_cast<const WfPool<R>*>(w.pool_dev), staged_shade)
                 if (tex) {  // interpreter variant: tables from global memory (rare scenes, fewer instantiations)
                     if (stats) RT_LAUNCH_SHADE(true, 0, true); else RT_LAUNCH_SHADE(false, 0, true);
                 } else if (stats) { if (lds_shade == 1) RT_LAUNCH_SHADE(true, 1, false); else if (lds_shade == 2) RT_LAUNCH_SHADE(true, 2, false); else RT_LAUNCH_SHADE(true, 0, false); }
@@ -1057,6 +1059,24 @@ static uint32_t owned_rows(uint32_t h, const RtRenderParams* p) {
     return n;
 }
 
+}  // namespace rt
+
+// Probe of fuzzy_reflection (rt_device.h): the routine with its fuzz == 0 shortcut next to the plain expression of
+// metal.rs:33-35 / glossy.rs:66-68, same inputs, same generator state (tests/test_gpu_parity.py).
+namespace rt {
+__global__ void k_debug_fuzzy_reflection(uint32_t n, const double* __restrict__ reflected, const double* __restrict__ fuzz,
+                                         const unsigned long long* __restrict__ state, double* __restrict__ out, unsigned long long* __restrict__ state_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3<double> r = mk<double>(reflected[3 * i], reflected[3 * i + 1], reflected[3 * i + 2]);
+    Rng a, b;
+    a.s = b.s = state[i];
+    const V3<double> da = fuzzy_reflection(r, fuzz[i], a);
+    const V3<double> db = r + random_unit<double>(b) * fuzz[i] * length(r);
+    out[6 * i + 0] = da.x; out[6 * i + 1] = da.y; out[6 * i + 2] = da.z;
+    out[6 * i + 3] = db.x; out[6 * i + 4] = db.y; out[6 * i + 5] = db.z;
+    state_out[2 * i] = a.s; state_out[2 * i + 1] = b.s;
+}
 }  // namespace rt
 
 extern "C" {
@@ -1200,6 +1220,28 @@ int rt_render(const RtScene* scene, const RtCameraDesc* camera, const RtRenderPa
     int r = render_host_impl(scene, camera, params, rgba_out);
     if (scene && scene->tail_flag) __atomic_store_n(scene->tail_flag, 1, __ATOMIC_RELEASE);  // also on the early error returns
     return r;
+}
+
+int rt_debug_fuzzy_reflection(int device, uint32_t n, const double* reflected, const double* fuzz, const uint64_t* state, double* out, uint64_t* state_out) {
+    using namespace rt;
+    if (!n || !reflected || !fuzz || !state || !out || !state_out) return set_err(RT_E_INVALID, "rt_debug_fuzzy_reflection: NULL argument");
+    HIP_TRY(hipSetDevice(device));
+    DeviceBuffers buf;
+    auto alloc = [&](size_t bytes, void** p) -> int { HIP_TRY(hipMalloc(p, bytes)); buf.allocs.push_back(*p); return RT_OK; };
+    void *d_r = nullptr, *d_f = nullptr, *d_s = nullptr, *d_o = nullptr, *d_so = nullptr;
+    int st;
+    if ((st = alloc(size_t(n) * 24, &d_r)) || (st = alloc(size_t(n) * 8, &d_f)) || (st = alloc(size_t(n) * 8, &d_s)) ||
+        (st = alloc(size_t(n) * 48, &d_o)) || (st = alloc(size_t(n) * 16, &d_so))) return st;
+    HIP_TRY(hipMemcpy(d_r, reflected, size_t(n) * 24, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_f, fuzz, size_t(n) * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_s, state, size_t(n) * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_fuzzy_reflection, dim3((n + 255) / 256), dim3(256), 0, nullptr, n, static_cast<const double*>(d_r), static_cast<const double*>(d_f),
+                       static_cast<const unsigned long long*>(d_s), static_cast<double*>(d_o), static_cast<unsigned long long*>(d_so));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d_o, size_t(n) * 48, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(state_out, d_so, size_t(n) * 16, hipMemcpyDeviceToHost));
+    return RT_OK;
 }
 
 // Diagnostic: traces ONE sample on the device and returns its radiance plus a per-bounce record

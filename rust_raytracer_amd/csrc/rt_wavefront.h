@@ -138,7 +138,7 @@ constexpr uint32_t WF_CHUNK = 2048;  // queue entries handled by one workgroup o
 constexpr uint32_t WF_BATCH = 256;   // queue entries a wave of a persistent kernel reserves at once
 
 // Appends `value` of the lanes with `pred` to an LDS list: ballot + mbcnt prefix, one LDS atomic per wave.
-RT_DEV void lds_append(bool pred, uint32_t value, uint32_t* list, uint32_t* count) {
+template <typename T> RT_DEV void lds_append(bool pred, T value, T* list, uint32_t* count) {
     unsigned long long m = __ballot(pred);
     if (m) {
         int leader = __ffsll((long long)m) - 1;
@@ -1167,10 +1167,11 @@ __global__ void __launch_bounds__(256, RT_MESH_WAVES) k_wf_mesh(SceneView<R> sc,
 // trigonometric functions of the UV maps are called out of line (uv_acos / uv_atan2 in rt_device.h: inlined, their polynomial
 // coefficients sat in 50 VGPRs for the whole kernel); 166 and 3 waves before that, 188-197 and 2 waves in round 1.  The
 // texture-interpreter variants need 174-189: no cap.
+constexpr uint32_t kShadeListBytes = 2u * WF_CHUNK * 2u + 8u * 4u;  // k_wf_shade's LDS in front of the staged tables: two lists of 16-bit entries, counters
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 5
 #endif
-#define RT_SHADE_BOUNDS __launch_bounds__(256, TEX ? 1 : (LDS == 1 && !STATS ? RT_SHADE_WAVES : 4))
+#define RT_SHADE_BOUNDS __launch_bounds__(256, TEX ? 1 : (!STATS ? RT_SHADE_WAVES : 4))
 
 // Diagnostic build (-DRT_SHADE_STAMPS, tools/gpu_shade_stamps.sh): where a wave of k_wf_shade spends its cycles.  s_memtime stamps
 // around the sections of a trip, summed per wave and added to g_shade_stamps at the end; never compiled into the product.
@@ -1192,9 +1193,11 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
                                            WfCounters* __restrict__ ctr, double* __restrict__ sample_L, DeviceCounters* counters,
                                            const WfPool<R>* __restrict__ pool_dev, uint32_t staged) {
     extern __shared__ __align__(16) char lds_raw[];
-    uint32_t* alive_list = reinterpret_cast<uint32_t*>(lds_raw);  // [WF_CHUNK] slots that go to the next queue
-    uint32_t* dead_list = alive_list + WF_CHUNK;                 // [WF_CHUNK] slots whose path ended
-    uint32_t* lc = dead_list + WF_CHUNK;                         // [0] n_alive [1] n_dead [2,3] sample base [4] queue base
+    // the lists hold positions inside this workgroup's chunk (16 bits): 8 KB instead of 16, so that up to 23 KB of tables fit the
+    // 32 KB that five workgroups per CU leave each other
+    uint16_t* alive_list = reinterpret_cast<uint16_t*>(lds_raw);  // [WF_CHUNK] entries that go to the next queue
+    uint16_t* dead_list = alive_list + WF_CHUNK;                 // [WF_CHUNK] entries whose path ended
+    uint32_t* lc = reinterpret_cast<uint32_t*>(dead_list + WF_CHUNK);  // [0] n_alive [1] n_dead [2,3] sample base [4] queue base
     char* tables = reinterpret_cast<char*>(lc + 8);
     if (threadIdx.x < 8) lc[threadIdx.x] = 0;
     SceneView<R> sc = sc_g;
@@ -1228,16 +1231,19 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
             best.t = at(pool.ht, slot); best.u = at(pool.hu, slot); best.v = at(pool.hv, slot);
             best.pc = at(pool.hpc, slot); best.tri = at(pool.htri, slot);
             // Resolve the hit BEFORE the rest of the path state is loaded: the compiler otherwise hoists those loads
-            // above resolve_hit's loops (texture walk, transform chain) and keeps more values live across them.
+            // above resolve_hit's loops (texture walk, transform chain) and keeps more values live across them (9 VGPRs that
+            // the kernel does not have at 5 waves per SIMD).  Requesting them with the ray and parking them in LDS meanwhile -
+            // one memory round trip less per trip - was measured: -3.5 % of the kernel on the default scene, +1..2 % on
+            // light_test / two_meshes, +-0 on the headline (profiles/r03/ab/shade_park_state.txt); not kept.
             HitInfo<R> hit{};
             if (best.pc >= 0) hit = resolve_hit<R, TEX>(sc, ps.ray, best);
             asm volatile("" ::: "memory");
             RT_STAMP(1);
             ps.throughput = mk<R>(at(pool.tr, slot), at(pool.tg, slot), at(pool.tb, slot));
-            ps.radiance = mk<R>(0, 0, 0);
             ps.depth = at(pool.depth, slot);
             Rng rng;
             rng.s = at(pool.rng, slot);
+            ps.radiance = mk<R>(0, 0, 0);
             bool cont;
             if (best.pc < 0) {  // camera.rs:331 background
                 ps.radiance = ps.throughput * ld3(prm.background);
@@ -1276,8 +1282,8 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
                 put_global(pw.rng, slot, rng.s);
             }
         }
-        lds_append(active && alive, slot, alive_list, &lc[0]);
-        lds_append(active && !alive, slot, dead_list, &lc[1]);
+        lds_append(active && alive, uint16_t(i - begin), alive_list, &lc[0]);
+        lds_append(active && !alive, uint16_t(i - begin), dead_list, &lc[1]);
         RT_STAMP(3);
     }
     __syncthreads();
@@ -1297,9 +1303,11 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
         const uint32_t j = j0 + threadIdx.x;
         bool restarted = false;
         uint32_t slot = 0;
+        uint16_t entry = 0;
         if (j < n_dead) {
             const unsigned long long s2 = s_base + j;
-            slot = dead_list[j];
+            entry = dead_list[j];
+            slot = full ? begin + entry : queue_in[begin + entry];
             if (s2 < grp.total) {
                 V3<R> o, d;
                 Rng rng;
@@ -1311,7 +1319,7 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
                 restarted = true;
             }
         }
-        lds_append(restarted, slot, alive_list, &lc[0]);
+        lds_append(restarted, entry, alive_list, &lc[0]);
     }
     RT_STAMP(5);
     __syncthreads();
@@ -1320,7 +1328,7 @@ __global__ void RT_SHADE_BOUNDS k_wf_shade(SceneView<R> sc_g, CameraView<R> cam,
     if (threadIdx.x == 0 && n_alive) lc[4] = atomicAdd(&ctr->n_out, n_alive);
     __syncthreads();
     const uint32_t qb = lc[4];
-    for (uint32_t j = threadIdx.x; j < n_alive; j += blockDim.x) queue_out[qb + j] = alive_list[j];
+    for (uint32_t j = threadIdx.x; j < n_alive; j += blockDim.x) queue_out[qb + j] = full ? begin + alive_list[j] : queue_in[begin + alive_list[j]];
     RT_STAMP(6);
 #ifdef RT_SHADE_STAMPS
     if ((threadIdx.x & 63u) == 0) {

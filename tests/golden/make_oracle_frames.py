@@ -34,6 +34,7 @@ CASES = {
     "nested_lights": ["tests/scenes/nested_lights", "-w=48", "-s=16", "--seed=23"],
     "deep_texture": ["tests/scenes/deep_texture", "-w=48", "-s=16", "--seed=24"],
     "two_meshes": ["tests/scenes/two_meshes", "-w=48", "-s=16", "--seed=11"],
+    "polished": ["tests/scenes/polished", "-w=48", "-s=16", "--seed=26"],  # Metal / Glossy with fuzz 0 (fuzzy_reflection's shortcut)
 }
 
 

@@ -50,6 +50,8 @@ SCENES = {
     "cornell_smoke": ["scenes/cornell_smoke", "-w=48", "-s=16", "--seed=21"],
     # a volume inside another volume's boundary, a plain volume, and a mesh BEHIND them (k_wf_prims<VOL> + k_wf_mesh)
     "nested_volumes": ["tests/scenes/nested_volumes", "-w=48", "-s=16", "--seed=22"],
+    # polished Metal / Glossy (fuzz 0: the kernels skip the normal samples of the random term) beside rough ones
+    "polished": ["tests/scenes/polished", "-w=48", "-s=16", "--seed=26"],
     # ObjectLists three levels deep inside `lights` (with an empty list and a non-light member)
     "nested_lights": ["tests/scenes/nested_lights", "-w=48", "-s=16", "--seed=23"],
     # a texture expression with more live values than the interpreter's four registers (spilled stack)
@@ -697,3 +699,37 @@ def test_render_device_keeps_frame_in_hbm(dev):
         scene.render_device(hs.camera, hs.params, out.data_ptr(), stream.cuda_stream)
     stream.synchronize()
     np.testing.assert_array_equal(out.cpu().numpy(), scene.render(hs.camera, hs.params))
+
+
+def test_specular_reflection_shortcut_is_bit_exact(dev):
+    """Metal / Glossy reflect into `reflected + random_unit * fuzz * |reflected|`.  For fuzz == 0 the kernels return `reflected`
+    and move the generator on by the six draws of the three normal samples (rt_device.h fuzzy_reflection) - unless a component
+    of `reflected` is a zero (the sum can turn -0 into +0) or so large that the length overflows (0 * inf = NaN).  The device
+    probe evaluates the routine and the plain expression on the same inputs: same bits, same generator state, for random and
+    for special operands."""
+    import ctypes as C
+    lib = api.load_device_lib()
+    lib.rt_debug_fuzzy_reflection.argtypes = [C.c_int, C.c_uint32] + [C.c_void_p] * 5
+    lib.rt_debug_fuzzy_reflection.restype = C.c_int
+    rng = np.random.default_rng(7)
+    special = np.array([0.0, -0.0, 1.0, -1.0, 0.5, 1e-320, -1e-320, 1e149, 1e151, -1e151, 1e308, np.inf, -np.inf, np.nan, 3.7e-9])
+    grid = np.stack(np.meshgrid(special, special, special, indexing="ij"), axis=-1).reshape(-1, 3)
+    rand = rng.standard_normal((200000, 3)) * 10.0 ** rng.integers(-6, 6, (200000, 1))
+    reflected = np.ascontiguousarray(np.concatenate([grid, grid, rand, rand[:20000]]), dtype=np.float64)
+    fuzz = np.concatenate([np.zeros(len(grid)), np.full(len(grid), -0.0), np.zeros(len(rand)), rng.uniform(0.0, 1.0, 20000)])
+    fuzz[len(grid) * 2 + 100000:len(grid) * 2 + 100050] = np.array([0.3, 1.0, 1e-300, np.nan, np.inf] * 10)
+    n = len(reflected)
+    state = rng.integers(0, 2 ** 63, n, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    out = np.zeros((n, 6), dtype=np.float64)
+    state_out = np.zeros((n, 2), dtype=np.uint64)
+    st = lib.rt_debug_fuzzy_reflection(0, n, reflected.ctypes.data, np.ascontiguousarray(fuzz).ctypes.data, state.ctypes.data,
+                                       out.ctypes.data, state_out.ctypes.data)
+    assert st == api.RT_OK, lib.rt_last_error().decode()
+    a, b = out[:, :3], out[:, 3:]
+    same = (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), f"{int((~same).any(axis=1).sum())} of {n} directions differ, first: {reflected[np.flatnonzero((~same).any(axis=1))[0]]}"
+    assert (state_out[:, 0] == state_out[:, 1]).all()
+    # the shortcut was taken where it may be: the generator moved on although the direction is `reflected` itself
+    plain = (fuzz == 0) & np.isfinite(reflected).all(axis=1) & (reflected != 0).all(axis=1) & (np.abs(reflected) < 1e150).all(axis=1)
+    assert plain.sum() > 200000 and (a[plain].view(np.uint64) == reflected[plain].view(np.uint64)).all()
+    assert (state_out[:, 0] == state + np.uint64(6) * np.uint64(0x9E3779B97F4A7C15)).all()
