@@ -228,6 +228,8 @@ typedef struct RtRenderStats {
     uint64_t bytes_state_shade;
     uint32_t n_iterations;        /* wavefront iterations (one bounce of every live path each)             */
     uint32_t n_replica_groups;    /* groups the replicas were rendered in (per-sample buffer budget)       */
+    uint32_t n_tail_compactions;  /* times the live paths were moved together at the end of a group (k_wf_compact) */
+    uint32_t _reserved;
 } RtRenderStats;
 
 typedef struct RtScene RtScene;

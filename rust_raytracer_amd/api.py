@@ -114,7 +114,8 @@ class RtRenderStats(C.Structure):
                 ("bytes_state", C.c_uint64),
                 ("prims_kernel_ms", C.c_double), ("shade_kernel_ms", C.c_double),
                 ("bytes_state_prims", C.c_uint64), ("bytes_state_shade", C.c_uint64),
-                ("n_iterations", C.c_uint32), ("n_replica_groups", C.c_uint32)]
+                ("n_iterations", C.c_uint32), ("n_replica_groups", C.c_uint32),
+                ("n_tail_compactions", C.c_uint32), ("_reserved", C.c_uint32)]
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_}

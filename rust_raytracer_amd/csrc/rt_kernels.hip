@@ -554,6 +554,8 @@ struct RtScene {
         std::vector<void*> allocs;
         void* pool_view = nullptr;     // host copy of WfPool<R>
         void* pool_dev = nullptr;      // the same descriptor in device memory (k_wf_shade re-reads the array bases from it)
+        void* pool2_view = nullptr;    // the second pool, 3/4 of the slots: destination of the first tail compaction (k_wf_compact),
+        void* pool2_dev = nullptr;     // after which the two take turns
         uint32_t* queue[2] = {nullptr, nullptr};
         uint32_t* mesh_queue = nullptr;
         void* mesh_spill = nullptr;        // k_wf_mesh: stack levels beyond the LDS part
@@ -666,8 +668,12 @@ static void wf_release_pool(RtScene::Wavefront& w) {
     w.allocs.clear();
     ::operator delete(w.pool_view);
     w.pool_view = nullptr;
+    ::operator delete(w.pool2_view);
+    w.pool2_view = nullptr;
     if (w.pool_dev) (void)hipFree(w.pool_dev);
     w.pool_dev = nullptr;
+    if (w.pool2_dev) (void)hipFree(w.pool2_dev);
+    w.pool2_dev = nullptr;
     for (int q = 0; q < 2; q++) {
         if (w.queue[q]) (void)hipFree(w.queue[q]);
         w.queue[q] = nullptr;
@@ -684,21 +690,31 @@ int wf_ensure(RtScene* s, uint32_t capacity) {
     auto* pool = new WfPool<R>();
     w.pool_view = pool;
     pool->capacity = capacity;
+    auto* pool2 = new WfPool<R>();
+    w.pool2_view = pool2;
+    pool2->capacity = std::max<uint32_t>(64u, uint32_t((uint64_t(capacity) * 3 + 3) / 4));  // a compaction happens below RT_WF_COMPACT_PCT <= 75 % of the addressed slots
     auto alloc = [&](size_t bytes, void** out) -> int {
         HIP_TRY(hipMalloc(out, bytes));
         w.allocs.push_back(*out);
         return RT_OK;
     };
-    auto build = [&]() -> int {
-        R** reals[] = {&pool->ox, &pool->oy, &pool->oz, &pool->dx, &pool->dy, &pool->dz, &pool->tr, &pool->tg, &pool->tb,
-                       &pool->ht, &pool->hu, &pool->hv};
+    auto build_pool = [&](WfPool<R>* pl) -> int {
+        const size_t cap = pl->capacity;
+        R** reals[] = {&pl->ox, &pl->oy, &pl->oz, &pl->dx, &pl->dy, &pl->dz, &pl->tr, &pl->tg, &pl->tb, &pl->ht, &pl->hu, &pl->hv};
         for (R** r : reals)
-            if (int st = alloc(size_t(capacity) * sizeof(R), reinterpret_cast<void**>(r))) return st;
-        if (int st = alloc(size_t(capacity) * 8, reinterpret_cast<void**>(&pool->rng))) return st;
-        if (int st = alloc(size_t(capacity) * 8, reinterpret_cast<void**>(&pool->sample))) return st;
-        if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->depth))) return st;
-        if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->hpc))) return st;
-        if (int st = alloc(size_t(capacity) * 4, reinterpret_cast<void**>(&pool->htri))) return st;
+            if (int st = alloc(cap * sizeof(R), reinterpret_cast<void**>(r))) return st;
+        if (int st = alloc(cap * 8, reinterpret_cast<void**>(&pl->rng))) return st;
+        if (int st = alloc(cap * 8, reinterpret_cast<void**>(&pl->sample))) return st;
+        if (int st = alloc(cap * 4, reinterpret_cast<void**>(&pl->depth))) return st;
+        if (int st = alloc(cap * 4, reinterpret_cast<void**>(&pl->hpc))) return st;
+        if (int st = alloc(cap * 4, reinterpret_cast<void**>(&pl->htri))) return st;
+        return RT_OK;
+    };
+    auto build = [&]() -> int {
+        if (int st = build_pool(pool)) return st;
+        if (int st = build_pool(pool2)) return st;
+        HIP_TRY(hipMalloc(&w.pool2_dev, sizeof(WfPool<R>)));
+        HIP_TRY(hipMemcpy(w.pool2_dev, pool2, sizeof(WfPool<R>), hipMemcpyHostToDevice));
         for (int q = 0; q < 2; q++) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.queue[q]), size_t(capacity) * 4));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&w.mesh_queue), size_t(capacity) * 4));
         HIP_TRY(hipMalloc(&w.pool_dev, sizeof(WfPool<R>)));
@@ -749,7 +765,9 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     if (capacity < 64) capacity = 64;
     if (int st = wf_ensure<R>(s, capacity)) return st;
     RtScene::Wavefront& w = s->wf;
-    WfPool<R> pool = *static_cast<WfPool<R>*>(w.pool_view);
+    WfPool<R> pool = *static_cast<WfPool<R>*>(w.pool_view);   // the pool the kernels are working on (changes at a tail compaction)
+    const WfPool<R> pool_a = pool, pool_b = *static_cast<WfPool<R>*>(w.pool2_view);
+    const void* pool_dev_cur = w.pool_dev;
 
     // per-sample radiance buffer: as many replicas per group as the memory budget allows
     size_t free_b = 0, total_b = 0;
@@ -854,6 +872,11 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     // and only while five workgroups still fit a CU's 160 KB next to its lists (<= 23 KB of tables; RT_LDS_SHADE_MAX overrides)
     const uint32_t shade_tables_max = env_u32("RT_LDS_SHADE_MAX", 32u * 1024u - kShadeListBytes);
     const int lds_shade = (staged_shade != 0 && staged_shade == ds.view.lay_shade.total_bytes && staged_shade <= shade_tables_max) ? 1 : (env_u32("RT_LDS_SHADE_PREFIX", 0) && staged_shade ? 2 : 0);
+    // tail compaction: RT_WF_COMPACT=0 keeps the paths where they are (A/B, tests), RT_WF_COMPACT_MIN = fewest paths worth a launch
+    const bool compact_tail = env_u32("RT_WF_COMPACT", 1) != 0;
+    const uint32_t compact_min = std::max<uint32_t>(1u, env_u32("RT_WF_COMPACT_MIN", 1024));
+    const uint32_t compact_pct = std::min<uint32_t>(75u, std::max<uint32_t>(1u, env_u32("RT_WF_COMPACT_PCT", 75)));  // ... when at most this share of the addressed slots is alive (50 / 62 / 75: tail of C2 13.0 / 12.4 / 11.9 ms)
+    uint32_t n_compactions = 0;
     const bool iter_log = env_u32("RT_WF_ITER_LOG", 0) != 0;
     const bool trace_pool = env_u32("RT_WF_TRACE", 0) != 0;  // debug: dump the first pool slots after every iteration
     const uint32_t check_every = trace_pool ? 1u : std::min<uint32_t>(32u, std::max<uint32_t>(1u, env_u32("RT_WF_CHECK", 8)));  // 4 timing events per iteration, 128 events
@@ -880,6 +903,9 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
         grp.strata = strata;
         if (grp.total >= (1ull << 51)) return set_err(RT_E_UNSUPPORTED, "more than 2^51 samples in one replica group");
         uint32_t first = uint32_t(std::min<uint64_t>(capacity, grp.total));
+        pool = pool_a;
+        pool_dev_cur = w.pool_dev;
+        bool on_b = false;
         pool.capacity = first;  // slots in use by this group: the kernels address slots directly while all of them are queued
         WfCounters init{};
         init.n_in = first;
@@ -909,7 +935,11 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
             size_t ev = 0;
             // near the end of the last group the host looks after every second iteration, so that the tail is seen when it starts
             const bool near_end = s->tail_flag && t0 + nrep >= T && w.h_ctr->next_sample + 4ull * pool.capacity >= grp.total;
-            const uint32_t check_now = near_end ? std::min<uint32_t>(check_every, 2u) : check_every;
+            // tail compaction wants to see the queue length of every iteration once the samples have run out, and to notice
+            // within two iterations that they have (a quarter of the slots restarts per iteration)
+            const bool all_started = w.h_ctr->next_sample >= grp.total;
+            const bool closing = compact_tail && w.h_ctr->next_sample + 2ull * pool.capacity >= grp.total;
+            const uint32_t check_now = (compact_tail && all_started) ? 1u : ((near_end || closing) ? std::min<uint32_t>(check_every, 2u) : check_every);
             for (uint32_t k = 0; k < check_now; k++) {
                 HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 if (split || prims_only) {
@@ -925,7 +955,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
 #undef RT_LAUNCH_ISECT
                     HIP_TRY(hipEventRecord(w.events[ev++], stream));
                 }
-#define RT_LAUNCH_SHADE(ST, L, TX) hipLaunchKernelGGL((k_wf_shade<R, ST, L, TX>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), (L ? size_t(staged_shade) : size_t(0)) + kShadeListBytes + shade_lds_pad, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters, static_cast<const WfPool<R>*>(w.pool_dev), staged_shade)
+#define RT_LAUNCH_SHADE(ST, L, TX) hipLaunchKernelGGL((k_wf_shade<R, ST, L, TX>), dim3((upper + WF_CHUNK - 1) / WF_CHUNK), dim3(256), (L ? size_t(staged_shade) : size_t(0)) + kShadeListBytes + shade_lds_pad, stream, ds.view, cv, pv, pool, grp, w.queue[qi], w.queue[qi ^ 1], w.d_ctr, w.sample_L, s->d_counters, static_cast<const WfPool<R>*>(pool_dev_cur), staged_shade)
                 if (tex) {  // interpreter variant: tables from global memory (rare scenes, fewer instantiations)
                     if (stats) RT_LAUNCH_SHADE(true, 0, true); else RT_LAUNCH_SHADE(false, 0, true);
                 } else if (stats) { if (lds_shade == 1) RT_LAUNCH_SHADE(true, 1, false); else if (lds_shade == 2) RT_LAUNCH_SHADE(true, 2, false); else RT_LAUNCH_SHADE(true, 0, false); }
@@ -951,7 +981,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
                                  it_ms[0], it_ms[1], it_ms[2]);
             }
             if (trace_pool) {
-                const uint32_t n = std::min<uint32_t>(first, env_u32("RT_WF_TRACE", 0));
+                const uint32_t n = std::min<uint32_t>(std::min(first, pool.capacity), env_u32("RT_WF_TRACE", 0));
                 std::vector<R> a[12];
                 R* src[12] = {pool.ox, pool.oy, pool.oz, pool.dx, pool.dy, pool.dz, pool.tr, pool.tg, pool.tb, pool.ht, pool.hu, pool.hv};
                 for (int k = 0; k < 12; k++) { a[k].resize(n); HIP_TRY(hipMemcpy(a[k].data(), src[k], n * sizeof(R), hipMemcpyDeviceToHost)); }
@@ -976,6 +1006,17 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
             // fill the GPU any more, the next frame's render (another RtScene, another stream) may start underneath it
             if (s->tail_flag && t0 + nrep >= T && upper < first) __atomic_store_n(s->tail_flag, 1, __ATOMIC_RELEASE);
             if (upper == 0) break;
+            // ---- tail compaction (rt_wavefront.h k_wf_compact): fewer than half of the addressed slots are alive and none will
+            //      restart: the live paths move to slots 0 .. upper-1 of the other pool, which becomes the pool ----
+            if (compact_tail && w.h_ctr->next_sample >= grp.total && upper >= compact_min && uint64_t(upper) * 100 <= uint64_t(pool.capacity) * compact_pct) {
+                WfPool<R> dst = on_b ? pool_a : pool_b;
+                hipLaunchKernelGGL((k_wf_compact<R>), dim3((upper + 255) / 256), dim3(256), 0, stream, pool, dst, w.queue[qi], upper);
+                on_b = !on_b;
+                pool = dst;
+                pool.capacity = upper;  // n_in == capacity: the kernels address slot i for entry i again
+                pool_dev_cur = on_b ? w.pool2_dev : w.pool_dev;
+                n_compactions++;
+            }
         }
 #undef RT_LAUNCH_PRIMS_ANY
 #undef RT_LAUNCH_PRIMS
@@ -1012,6 +1053,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     st.n_launches = isect_launches;
     st.n_iterations = isect_launches;
     st.n_replica_groups = n_groups;
+    st.n_tail_compactions = n_compactions;
     if (stats && split && env_u32("RT_WF_DEBUG", 0)) {
         auto pct = [](unsigned long long lanes, unsigned long long waves) { return waves ? 100.0 * double(lanes) / (64.0 * double(waves)) : 0.0; };
         std::fprintf(stderr,

@@ -124,6 +124,27 @@ __global__ void __launch_bounds__(256) k_wf_generate(WfPool<R> pool, uint32_t co
     queue[i] = i;
 }
 
+// Tail compaction.  Once every sample of a replica group has been started, finished slots stay empty and the queue is a
+// thinning, near-random subset of the pool: the kernels then read and write whole 128-byte lines for the one or two live
+// slots in them, and their time stops following the number of paths (k_wf_shade takes 1.3 ms for 18 M and for 4 M paths of a
+// 22 M pool; a fifth of a small frame is spent this way, profiles/r03/tail_compaction.txt).  Whenever fewer than half the
+// addressed slots are alive, this kernel copies the live paths - ray, weight, depth, generator, sample index; the hit record is
+// recomputed by the next search - into slots 0 .. n-1 of the OTHER pool, which becomes the pool: n == capacity again, i.e. the
+// identity order with unit-stride accesses.  A path does not care which slot holds it (its generator and its sample index
+// travel with it), so frames do not change.
+template <typename R>
+__global__ void __launch_bounds__(256) k_wf_compact(WfPool<R> src, WfPool<R> dst, const uint32_t* __restrict__ queue, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = queue[i];
+    at(dst.ox, i) = at(src.ox, s); at(dst.oy, i) = at(src.oy, s); at(dst.oz, i) = at(src.oz, s);
+    at(dst.dx, i) = at(src.dx, s); at(dst.dy, i) = at(src.dy, s); at(dst.dz, i) = at(src.dz, s);
+    at(dst.tr, i) = at(src.tr, s); at(dst.tg, i) = at(src.tg, s); at(dst.tb, i) = at(src.tb, s);
+    at(dst.rng, i) = at(src.rng, s);
+    at(dst.sample, i) = at(src.sample, s);
+    at(dst.depth, i) = at(src.depth, s);
+}
+
 // Number of lanes below `lane` whose bit is set in `mask` (v_mbcnt_lo/hi).
 RT_DEV uint32_t lane_prefix(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));

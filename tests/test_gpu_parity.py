@@ -734,3 +734,40 @@ def test_specular_reflection_shortcut_is_bit_exact(dev):
     assert plain.sum() > 200000 and (a[plain].view(np.uint64) == reflected[plain].view(np.uint64)).all()
     six_draws = np.uint64((6 * 0x9E3779B97F4A7C15) % 2 ** 64)  # SplitMix64 adds its increment once per draw (wrapping)
     assert (state_out[:, 0] == state + six_draws).all()
+
+
+@pytest.mark.parametrize("name", ["cornell", "light_test", "two_meshes", "cornell_smoke", "default"])
+def test_tail_compaction_does_not_change_the_frame(dev, name, monkeypatch):
+    """When a replica group's samples have all been started, the wavefront scheduler moves the surviving paths together
+    (k_wf_compact: into slots 0 .. n-1 of a second pool, whenever fewer than half the addressed slots are alive), so that the last
+    iterations keep unit-stride accesses.  A path carries its generator and sample index with it: the frame must be the one
+    without compaction and the megakernel's, bit for bit - with the default pool, with a small one (several compactions, every
+    kernel in both addressing modes) and with replica groups (a tail per group, back to the first pool each time)."""
+    hs = api.HostScene(SCENES[name][:-2] + ["-s=64", "-t=3", "--seed=31"])
+    scene = api.DeviceScene(hs.desc, 0)
+    p = hs.params.copy()
+    p.pipeline = api.RT_PIPELINE_MEGAKERNEL
+    mega = scene.render(hs.camera, p)
+    p.pipeline = api.RT_PIPELINE_WAVEFRONT
+    for pool, sample_gb in (("0", None), ("16384", None), ("3000", "0")):
+        frames = {}
+        for compact in ("1", "0"):
+            monkeypatch.setenv("RT_WF_COMPACT", compact)
+            monkeypatch.setenv("RT_WF_COMPACT_MIN", "64")
+            if pool != "0":
+                monkeypatch.setenv("RT_WF_POOL", pool)
+            if sample_gb is not None:
+                monkeypatch.setenv("RT_WF_SAMPLE_GB", sample_gb)
+            frames[compact] = scene.render(hs.camera, p)
+            st = scene.stats()
+            if compact == "1":
+                assert st.n_tail_compactions >= (2 if pool != "0" else 1), (pool, st.n_tail_compactions)
+                if sample_gb is not None:
+                    assert st.n_replica_groups == 3 and st.n_tail_compactions >= 3
+            else:
+                assert st.n_tail_compactions == 0
+        for compact, wf in frames.items():
+            same = (wf == mega) | (np.isnan(wf) & np.isnan(mega))
+            assert same.all(), f"pool {pool}, RT_WF_COMPACT={compact}: {int((~same).any(axis=2).sum())} pixels differ from the megakernel"
+        monkeypatch.delenv("RT_WF_POOL", raising=False)
+        monkeypatch.delenv("RT_WF_SAMPLE_GB", raising=False)

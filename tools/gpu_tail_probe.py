@@ -1,28 +1,41 @@
-"""What the tail of a render costs: one rank's share (part 0 of 8, as bench.py --gpus 8 partitions it) of the headline frame
-with the per-iteration log of the wavefront driver (RT_WF_ITER_LOG=1, host check after every iteration)."""
-import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["RT_WF_ITER_LOG"] = "1"
-os.environ["RT_WF_CHECK"] = "1"
-import torch
-from rust_raytracer_amd import api
-from rust_raytracer_amd import dist as rtdist
+"""Where does the end of a render go?  Per-iteration kernel times of the wavefront scheduler (RT_WF_ITER_LOG=1, RT_WF_CHECK=1:
+the host looks after every iteration, so the queue length printed is the iteration's own) for a whole small frame (C2) and
+for one rank's share of the headline frame on 8 GPUs; prints the time spent in iterations below a number of queued paths."""
+import os, subprocess, sys, re
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CODE = r'''
+import sys, os
+sys.path.insert(0, %r)
 import bench
-bench.ensure_dragon()
-hs = api.HostScene(["scenes/cornell_dragon", "-w=1200", "-s=1000", "-t=10", "--seed=1"])
-scene = api.DeviceScene(hs.desc, 0)
-dev = torch.device("cuda", 0)
-p = rtdist.partition_params(hs.params, 8, 0, hs.height)
-rows = len(api.owned_rows(hs.height, p))
-out = torch.empty((rows, hs.width, 4), dtype=torch.float64, device=dev)
-st = torch.cuda.current_stream(dev)
-for rep in range(2):
-    sys.stderr.write(f"=== render {rep}\n"); sys.stderr.flush()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    scene.render_device(hs.camera, p, out.data_ptr(), st.cuda_stream)
-    torch.cuda.synchronize()
-    t = time.perf_counter() - t0
-s = scene.stats()
-print(f"1/8 share: rows {rows}, wall {t*1e3:.1f} ms, kernels {s.kernel_ms:.1f} ms (mesh {s.traversal_kernel_ms:.1f} shade {s.shade_kernel_ms:.1f} prims {s.prims_kernel_ms:.1f}), "
-      f"{s.n_iterations} iterations, {s.samples/1e6:.0f} M samples -> {s.samples/t/1e6:.0f} Msamples/s", flush=True)
+from rust_raytracer_amd import api, dist
+which = sys.argv[1]
+if which == "c2":
+    hs = api.HostScene(bench.WORKLOADS["c2"][0])
+    p = hs.params.copy()
+else:
+    bench.ensure_dragon()
+    hs = api.HostScene(bench.WORKLOADS["c4"][0])
+    p = dist.partition_params(hs.params, 8, 0, hs.camera.image_height)
+p.pipeline = api.RT_PIPELINE_WAVEFRONT
+sc = api.DeviceScene(hs.desc, 0)
+sc.render(hs.camera, p)      # untimed: allocations
+print("=== timed", flush=True)
+sys.stderr.write("=== timed\n"); sys.stderr.flush()
+sc.render(hs.camera, p)
+st = sc.stats()
+print("kernel_ms %%.2f iterations %%d" %% (st.kernel_ms, st.n_iterations))
+''' % REPO
+for which in (sys.argv[1:] or ["c2", "c4_share"]):
+    env = dict(os.environ, RT_WF_ITER_LOG="1", RT_WF_CHECK="1")
+    r = subprocess.run([sys.executable, "-c", CODE, which], env=env, capture_output=True, text=True)
+    err = r.stderr.split("=== timed")[-1]
+    rows = [(int(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4)))
+            for m in re.finditer(r"<= (\d+) paths queued: prims ([\d.]+) ms, traversal ([\d.]+) ms, shade ([\d.]+) ms", err)]
+    total = sum(a + b + c for _, a, b, c in rows)
+    print(which, r.stdout.strip().splitlines()[-1], "iterations logged", len(rows), "sum of kernel times %.2f ms" % total)
+    full = max(n for n, *_ in rows) if rows else 0
+    for lim in (full, full // 2, 4000000, 1000000, 262144, 65536, 16384):
+        sel = [(n, a, b, c) for n, a, b, c in rows if n < lim]
+        print("   iterations with < %9d paths queued: %3d, %.2f ms (%.1f %%)" % (lim, len(sel), sum(a + b + c for _, a, b, c in sel), 100.0 * sum(a + b + c for _, a, b, c in sel) / max(total, 1e-9)))
+    for n, a, b, c in (rows[-26:] if os.environ.get("RT_TAIL_ROWS") else []):
+        print("      %9d  prims %.3f  traversal %.3f  shade %.3f" % (n, a, b, c))
