@@ -746,17 +746,19 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     const uint32_t strata = p.sqrt_spt * p.sqrt_spt;
     const uint32_t T = p.thread_count;
     const uint64_t per_replica = uint64_t(strata) * npix;
-    // pool size: enough paths to keep every CU busy for several rounds per launch
     // Pool size.  Every launch of the persistent mesh kernel ends with a drain of ~0.4 ms (the longest remaining traversals:
-    // dependent fetches), so fewer, larger launches win — measured at full size (1.44 G samples), k_wf_mesh ms per step /
-    // Msamples/s: 16M 789 / 1067, 32M 731 / 1115, 64M 699 / 1144, 128M 686 / 1153, 256M 682 / 1128 — but the pool also is what
-    // drains at the end of a render (its paths die out over ~20 ever smaller iterations), which costs in proportion to its
-    // size: for one rank's share of an 8-way partition (180 M samples) 64M / 32M / 16M / 8M slots take 204 / 181 / 187 / 200 ms.
-    // launches ~ samples / pool and tail ~ pool: the best size grows with the square root of the work, 64M at 1.44 G samples.
+    // dependent fetches) and the streaming kernels run better in few large launches, so fewer, larger launches win; against that
+    // stands the tail: the pool is what drains at the end of a replica group, over ~20 ever smaller iterations.  Round 2 (tail at
+    // 2.5 x its work's worth): best size 64 M slots at 1.44 G samples, growing with the square root of the work.  Round 3's tail
+    // compaction (k_wf_compact) halved the tail's price and moved the optimum up - Msamples/s, same box (profiles/r03/tail_compaction.txt):
+    //   C4 1.44 G samples:  64 M 1256-1287, 96 M 1289-1293, 128 M 1312-1332, 160 M 1319-1338, 192 M 1326-1337, 256 M 1300-1311
+    //   C3 0.96 G: 52 M 4841, 80 M 4907, 96 M 4977, 112 M 4890      C1 0.25 G: 26 M 1962, 48 M 2028, 64 M 2061-2079, 96 M 2120, 128 M 2129
+    //   C2 0.16 G (no mesh): 16 M 1681, 22 M 1692, 32 M 1668, 44 M 1670      one of 8 ranks' share of C4: 23 M 157 ms, 46 M / 92 M 151, 128 M 153
+    // -> 128 M slots at 1.44 G samples, with the square root of the work below it (within 1-3 % of each workload's best).
     uint32_t capacity;
     {
         const double total_samples = double(per_replica) * double(T);
-        double c = 67108864.0 * std::sqrt(total_samples / 1.44e9);
+        double c = 134217728.0 * std::sqrt(total_samples / 1.44e9);
         c = std::fmin(std::fmax(c, 1048576.0), 134217728.0);
         capacity = env_u32("RT_WF_POOL", uint32_t(c) & ~0xFFFFFu);
     }
