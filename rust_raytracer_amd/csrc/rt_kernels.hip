@@ -877,7 +877,7 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     // tail compaction: RT_WF_COMPACT=0 keeps the paths where they are (A/B, tests), RT_WF_COMPACT_MIN = fewest paths worth a launch
     const bool compact_tail = env_u32("RT_WF_COMPACT", 1) != 0;
     const uint32_t compact_min = std::max<uint32_t>(1u, env_u32("RT_WF_COMPACT_MIN", 1024));
-    const uint32_t compact_pct = std::min<uint32_t>(75u, std::max<uint32_t>(1u, env_u32("RT_WF_COMPACT_PCT", 75)));  // ... when at most this share of the addressed slots is alive (50 / 62 / 75: tail of C2 13.0 / 12.4 / 11.9 ms)
+    const uint32_t compact_pct = std::min<uint32_t>(75u, std::max<uint32_t>(1u, env_u32("RT_WF_COMPACT_PCT", 50)));  // ... when at most this share of the addressed slots is alive.  50 / 62 / 75: the tail's iterations of C2 take 13.0 / 12.4 / 11.9 ms, but the paths thin out by ~22 % per iteration, so 75 compacts after nearly every one (13 copies of 0.3 ms per C2 frame, 6 with 50); whole frames are equal within the noise
     uint32_t n_compactions = 0;
     const bool iter_log = env_u32("RT_WF_ITER_LOG", 0) != 0;
     const bool trace_pool = env_u32("RT_WF_TRACE", 0) != 0;  // debug: dump the first pool slots after every iteration
