@@ -9,8 +9,12 @@ sys.path.insert(0, %r)
 import bench
 from rust_raytracer_amd import api, dist
 which = sys.argv[1]
-if which == "c2":
-    hs = api.HostScene(bench.WORKLOADS["c2"][0])
+if which in ("c2", "c1", "c3"):
+    hs = api.HostScene(bench.WORKLOADS[which][0])
+    p = hs.params.copy()
+elif which == "c4":
+    bench.ensure_dragon()
+    hs = api.HostScene(bench.WORKLOADS["c4"][0])
     p = hs.params.copy()
 else:
     bench.ensure_dragon()
@@ -37,5 +41,5 @@ for which in (sys.argv[1:] or ["c2", "c4_share"]):
     for lim in (full, full // 2, 4000000, 1000000, 262144, 65536, 16384):
         sel = [(n, a, b, c) for n, a, b, c in rows if n < lim]
         print("   iterations with < %9d paths queued: %3d, %.2f ms (%.1f %%)" % (lim, len(sel), sum(a + b + c for _, a, b, c in sel), 100.0 * sum(a + b + c for _, a, b, c in sel) / max(total, 1e-9)))
-    for n, a, b, c in (rows[-26:] if os.environ.get("RT_TAIL_ROWS") else []):
+    for n, a, b, c in (rows[-60:] if os.environ.get("RT_TAIL_ROWS") else []):
         print("      %9d  prims %.3f  traversal %.3f  shade %.3f" % (n, a, b, c))
