@@ -686,6 +686,8 @@ template <typename R>
 int wf_ensure(RtScene* s, uint32_t capacity) {
     RtScene::Wavefront& w = s->wf;
     if (w.capacity == capacity && w.real_size == sizeof(R)) return RT_OK;
+    if (const uint32_t limit = env_u32("RT_WF_FAKE_OOM_ABOVE", 0); limit && capacity > limit)  // tests: the out-of-memory path of render_wavefront
+        return set_err(RT_E_NOMEM, "path pool does not fit in device memory (RT_WF_FAKE_OOM_ABOVE)");
     wf_release_pool(w);
     auto* pool = new WfPool<R>();
     w.pool_view = pool;
@@ -694,7 +696,12 @@ int wf_ensure(RtScene* s, uint32_t capacity) {
     w.pool2_view = pool2;
     pool2->capacity = std::max<uint32_t>(64u, uint32_t((uint64_t(capacity) * 3 + 3) / 4));  // a compaction happens below RT_WF_COMPACT_PCT <= 75 % of the addressed slots
     auto alloc = [&](size_t bytes, void** out) -> int {
-        HIP_TRY(hipMalloc(out, bytes));
+        const hipError_t e = hipMalloc(out, bytes);
+        if (e == hipErrorOutOfMemory) {
+            (void)hipGetLastError();  // not sticky: the caller retries with a smaller pool
+            return set_err(RT_E_NOMEM, "path pool does not fit in device memory");
+        }
+        HIP_TRY(e);
         w.allocs.push_back(*out);
         return RT_OK;
     };
@@ -765,7 +772,14 @@ int render_wavefront(RtScene* s, DeviceScene<R>& ds, const RtCameraDesc& cam, co
     if (capacity > (1u << 28)) capacity = 1u << 28;  // the kernels address pool arrays through 32-bit byte offsets (rt_wavefront.h, at())
     if (uint64_t(capacity) > per_replica * T) capacity = uint32_t(per_replica * T);
     if (capacity < 64) capacity = 64;
-    if (int st = wf_ensure<R>(s, capacity)) return st;
+    // the pool is a matter of speed, not of correctness: when device memory is short (other scenes of a frame pipeline, other
+    // processes on the card) a smaller one renders the same frame
+    for (;;) {
+        const int st = wf_ensure<R>(s, capacity);
+        if (st == RT_OK) break;
+        if (st != RT_E_NOMEM || capacity <= (1u << 20) || std::getenv("RT_WF_POOL")) return st;
+        capacity = std::max<uint32_t>(1u << 20, (capacity / 2) & ~0xFFFFFu);
+    }
     RtScene::Wavefront& w = s->wf;
     WfPool<R> pool = *static_cast<WfPool<R>*>(w.pool_view);   // the pool the kernels are working on (changes at a tail compaction)
     const WfPool<R> pool_a = pool, pool_b = *static_cast<WfPool<R>*>(w.pool2_view);

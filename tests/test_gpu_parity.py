@@ -771,3 +771,25 @@ def test_tail_compaction_does_not_change_the_frame(dev, name, monkeypatch):
             assert same.all(), f"pool {pool}, RT_WF_COMPACT={compact}: {int((~same).any(axis=2).sum())} pixels differ from the megakernel"
         monkeypatch.delenv("RT_WF_POOL", raising=False)
         monkeypatch.delenv("RT_WF_SAMPLE_GB", raising=False)
+
+
+def test_a_pool_that_does_not_fit_is_halved(dev, monkeypatch):
+    """The path pool is sized for speed (128 M slots at the headline's work).  When device memory is short - other scenes of a
+    frame pipeline, other processes on the card - the scheduler halves it until it fits instead of failing; the frame is the
+    same (RT_WF_FAKE_OOM_ABOVE makes every pool above that many slots fail like hipErrorOutOfMemory)."""
+    hs = api.HostScene(["scenes/cornell", "-w=400", "-s=64", "--seed=3"])
+    scene = api.DeviceScene(hs.desc, 0)
+    p = hs.params.copy()
+    p.pipeline = api.RT_PIPELINE_WAVEFRONT
+    ref = scene.render(hs.camera, p)
+    it_ref = scene.stats().n_iterations
+    monkeypatch.setenv("RT_WF_FAKE_OOM_ABOVE", str(1 << 21))
+    scene2 = api.DeviceScene(hs.desc, 0)
+    out = scene2.render(hs.camera, p)
+    assert scene2.stats().n_iterations > it_ref        # a smaller pool: more iterations
+    assert ((out == ref) | (np.isnan(out) & np.isnan(ref))).all()
+    monkeypatch.setenv("RT_WF_POOL", str(1 << 23))      # an explicit size is taken as given: the error surfaces
+    scene3 = api.DeviceScene(hs.desc, 0)
+    with pytest.raises(api.RtError) as e:
+        scene3.render(hs.camera, p)
+    assert e.value.status == api.RT_E_NOMEM
