@@ -81,8 +81,10 @@ def test_frames_start_in_order_after_the_previous_tail(depth):
         if k >= depth:
             assert t[("start", k)] >= t[("end", k - depth)]        # a scene renders one frame at a time
     if depth > 1:
-        # tails overlap the next frame: the batch is shorter than n x (steady + tail)
-        assert elapsed < n * 0.06 * 0.9
+        # tails overlap the next frame: the batch is shorter than the frames one after the other would have been (their own
+        # measured durations, so that a loaded machine's longer sleeps do not matter)
+        one_after_the_other = sum(t[("end", k)] - t[("start", k)] for k in range(n))
+        assert elapsed < 0.95 * one_after_the_other
         assert any(t[("start", k)] < t[("end", k - 1)] for k in range(1, n))
 
 
